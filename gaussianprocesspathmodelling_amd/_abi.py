@@ -1,0 +1,98 @@
+"""ctypes binding of include/gpx.h — the only way the Python host reaches the GPU.
+
+There is deliberately no fallback: if ``csrc/libgpx.so`` is missing or does not load,
+``load()`` raises.  Nothing here imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgpx.so")
+ABI_VERSION = 1
+
+KERNEL_IDS = {"rbf": 0, "matern52": 1}
+DTYPE_IDS = {"float64": 0, "float32": 1}
+MEM_HOST, MEM_DEVICE = 0, 1
+FLAG_PROFILE = 1
+
+
+class GpxConfig(C.Structure):
+    _fields_ = [("kernel", C.c_int32), ("dtype", C.c_int32), ("device", C.c_int32),
+                ("block", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GpxTimings(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("h2d", "kbuild", "chol", "solve", "logdet", "fit_total",
+                 "kstar", "mean", "trsm", "var", "d2h", "predict_total",
+                 "comm", "chol_diag", "chol_trsm", "chol_syrk", "syrk_flops")] + \
+               [("syrk_launches", C.c_int64), ("kbuild_bytes", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/gpx.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_PD = C.POINTER(C.c_double)
+SIGNATURES = {
+    "gpx_abi_version": (C.c_int, []),
+    "gpx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gpx_create": (C.c_int, [C.POINTER(_P), C.POINTER(GpxConfig)]),
+    "gpx_destroy": (None, [_P]),
+    "gpx_last_error": (C.c_char_p, [_P]),
+    "gpx_fit": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _PD, C.c_int32,
+                          C.c_double, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_int64)]),
+    "gpx_predict": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
+    "gpx_get_alpha": (C.c_int, [_P, _P]),
+    "gpx_logdet": (C.c_int, [_P, _PD]),
+    "gpx_get_timings": (C.c_int, [_P, C.POINTER(GpxTimings)]),
+    "gpx_comm_unique_id": (C.c_int, [_P]),
+    "gpx_comm_init": (C.c_int, [_P, _P]),
+    "gpx_kernel_matrix": (C.c_int, [C.c_int32, _PD, C.c_int64, _PD, C.c_int64, C.c_int32, _PD,
+                                    C.c_int32, C.c_double, C.c_double, _PD]),
+    "gpx_potrf": (C.c_int, [_PD, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
+    "gpx_trsm": (C.c_int, [_PD, C.c_int64, _PD, C.c_int64]),
+    "gpx_gemm_nt": (C.c_int, [_PD, C.c_int64, C.c_int64, _PD, _PD, C.c_int64, C.c_int32]),
+    "gpx_mfma_probe": (C.c_int, [_PD, _PD, _PD]),
+    "gpx_microbench": (C.c_int, [_PD, _PD]),
+}
+
+_lib = None
+
+
+class GpxError(RuntimeError):
+    """Non-zero return code from libgpx (API misuse, HIP or RCCL failure)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libgpx error {code}: {message}")
+        self.code = code
+
+
+def load():
+    """dlopen csrc/libgpx.so and attach signatures.  Raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m gaussianprocesspathmodelling_amd.build` "
+            "(hipcc, gfx950). The GP engine has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.gpx_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"libgpx ABI version {v} != expected {ABI_VERSION}: rebuild the library")
+    _lib = lib
+    return lib
+
+
+def dptr(arr):
+    """numpy float64 array -> POINTER(c_double)"""
+    return arr.ctypes.data_as(_PD)

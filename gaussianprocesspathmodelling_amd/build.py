@@ -1,0 +1,59 @@
+"""Build recipe for libgpx.so (hipcc, gfx950 only, in-tree output).
+
+``python -m gaussianprocesspathmodelling_amd.build`` or ``__graft_entry__.build()``.
+The shared object lands next to its sources (``csrc/libgpx.so``) so that it travels
+with the repo snapshot to the GPU box; it is git-ignored.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+SOURCES = ["gpx_api.hip", "gpx_blas.hip", "gpx_kbuild.hip", "gpx_misc.hip"]
+HEADERS = ["gpx_internal.h", os.path.join("..", "..", "include", "gpx.h")]
+LIB = os.path.join(CSRC, "libgpx.so")
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libgpx.so cannot be built (no CPU fallback exists)")
+    return exe
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 and link libgpx.so."""
+    if not force and not needs_build():
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-c",
+               os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,717 @@
+// gpx_api.hip — host side of libgpx.so: the C ABI of include/gpx.h.
+//
+// Implements the fit()/predict() hot path of SURVEY.md §8 (rows a1-a6) on one MI355X:
+//   fit:     K = sf2 k(X,X) + (sn2+jitter) I  ->  blocked Cholesky (in place, lower)
+//            ->  alpha = L^-T L^-1 y  ->  logdet
+//   predict: K* = sf2 k(Xs,X) -> mean = K* alpha -> V^T = K* L^-T -> var = sf2 - rowsumsq(V^T)
+// The reference has no such path (GPmap.py has no fit/predict/linalg beyond
+// np.linalg.norm at GPmap.py:120); the arithmetic follows oracle/gp_oracle.py
+// (R&W Alg. 2.1).
+//
+// Data layout in HBM (all fp64, row-major):
+//   K / L   [Npad][ld]   ld = Npad + 16 (skewed against power-of-two strides); only the
+//                        lower triangle is referenced; rows/cols >= N are identity
+//   Winv    [Npad/64][64][64]   inverses of the 64x64 diagonal blocks of L
+//   P       [Npad][nb+16]       compact copy of the current panel (SYRK operand)
+//   YT      [64][ld]            right-hand sides / alpha, transposed (row r = target r)
+//   VT      [Mpad][ld]          K* and, after the forward solve, V^T
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gpx.h"
+#include "gpx_internal.h"
+
+using namespace gpx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr int RHS_ROWS = 64;  // right-hand sides are padded to one 64-row MFMA slab
+
+struct Phase {
+  hipEvent_t a, b;
+  double* target;
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct gpx_handle {
+  gpx_config cfg{};
+  int nb = 512;
+  hipStream_t st = nullptr;
+  std::string err;
+  gpx_timings tm{};
+  // fitted state
+  bool fitted = false;
+  int64_t N = 0, Npad = 0, ld = 0, ldp = 0;
+  int d = 0, k = 0, n_ls = 1;
+  double sf2 = 0, sn2 = 0, jitter = 0;
+  double logdet = 0;
+  DevBuf X, Xs, ls, K, Winv, P, YT, Y, scalars, info;
+  // predict state
+  DevBuf Q, Qs, VT, MT, var, meanout;
+  // event pool
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<Phase> phases;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                    \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      char buf_[512];                                                                      \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+               __FILE__, __LINE__);                                                        \
+      (h)->err = buf_;                                                                     \
+      return e_ == hipErrorOutOfMemory ? GPX_E_NOMEM : GPX_E_HIP;                          \
+    }                                                                                      \
+  } while (0)
+
+int fail(gpx_handle* h, int code, const char* msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+
+int ensure(gpx_handle* h, DevBuf& b, size_t bytes) {
+  if (b.cap >= bytes && b.p) return GPX_OK;
+  if (b.p) HIPCHK(h, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  HIPCHK(h, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return GPX_OK;
+}
+
+void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+hipEvent_t next_event(gpx_handle* h) {
+  if (h->ev_used == h->ev_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    h->ev_pool.push_back(e);
+  }
+  return h->ev_pool[h->ev_used++];
+}
+
+struct PhaseScope {
+  gpx_handle* h;
+  Phase ph;
+  bool on;
+  PhaseScope(gpx_handle* h_, double* target, bool enable = true) : h(h_), on(enable) {
+    if (!on) return;
+    ph.a = next_event(h);
+    ph.b = next_event(h);
+    ph.target = target;
+    if (ph.a) (void)hipEventRecord(ph.a, h->st);
+  }
+  ~PhaseScope() {
+    if (!on) return;
+    if (ph.b) (void)hipEventRecord(ph.b, h->st);
+    if (ph.a && ph.b) h->phases.push_back(ph);
+  }
+};
+
+// after the stream is idle: fold event pairs into their targets
+void collect_phases(gpx_handle* h) {
+  for (auto& p : h->phases) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) *p.target += ms;
+  }
+  h->phases.clear();
+  h->ev_used = 0;
+}
+
+// ---- blocked right-looking Cholesky, in place on the lower triangle -------------------
+// A [n][ld]; Winv [n/64][64*64]; P [n][ldp] compact panel; n multiple of 64 (128 when
+// n > nb).  Two levels: panels of width nb; inside a panel's diagonal block, 64-wide
+// sub-panels whose diagonal is factorised by the one-workgroup POTF2.
+void chol_enqueue(gpx_handle* h, double* A, int64_t ld, int64_t n, int nb, double* Winv, double* P,
+                  int64_t ldp, int* info, int64_t gidx0, bool profile) {
+  hipStream_t st = h->st;
+  for (int64_t o = 0; o < n; o += nb) {
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    {
+      PhaseScope ps(h, &h->tm.chol_diag, profile);
+      for (int q = 0; q < nbp / KB; ++q) {
+        const int64_t oq = o + (int64_t)q * KB;
+        double* Aqq = A + oq * ld + oq;
+        double* Wq = Winv + (oq / KB) * (KB * KB);
+        launch_potf2_64(Aqq, ld, Wq, gidx0 + oq, info, st);
+        const int64_t rem = o + nbp - (oq + KB);
+        if (rem > 0) {
+          double* panel = A + (oq + KB) * ld + oq;
+          launch_trsm_rlt(panel, ld, rem, Aqq, ld, Wq, KB, nullptr, 0, st);
+          launch_gemm_nt(64, A + (oq + KB) * ld + (oq + KB), ld, panel, ld, panel, ld, rem, rem, KB,
+                         1, 0, st);
+        }
+      }
+    }
+    const int64_t ntrail = n - (o + nbp);
+    if (ntrail > 0) {
+      double* panel = A + (o + nbp) * ld + o;
+      {
+        PhaseScope ps(h, &h->tm.chol_trsm, profile);
+        launch_trsm_rlt(panel, ld, ntrail, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, P,
+                        ldp, st);
+      }
+      {
+        PhaseScope ps(h, &h->tm.chol_syrk, profile);
+        const int tile = (ntrail % 128 == 0) ? 128 : 64;
+        launch_gemm_nt(tile, A + (o + nbp) * ld + (o + nbp), ld, P, ldp, P, ldp, ntrail, ntrail, nbp,
+                       1, 0, st);
+      }
+      h->tm.syrk_flops += (double)ntrail * (double)(ntrail + 1) * (double)nbp;
+      h->tm.syrk_launches += 1;
+    }
+  }
+}
+
+// XT (rows x n, ld) <- XT * L^-T   (i.e. X <- L^-1 X for X = XT^T), block forward substitution
+void solve_fwd_enqueue(gpx_handle* h, double* XT, int64_t rows, const double* L, int64_t ld,
+                       int64_t n, int nb, const double* Winv) {
+  hipStream_t st = h->st;
+  const int tile = (rows % 128 == 0) ? 128 : 64;
+  for (int64_t o = 0; o < n; o += nb) {
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    launch_trsm_rlt(XT + o, ld, rows, L + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, nullptr,
+                    0, st);
+    const int64_t ntrail = n - (o + nbp);
+    if (ntrail > 0)
+      launch_gemm_nt((ntrail % 128 == 0) ? tile : 64, XT + o + nbp, ld, XT + o, ld,
+                     L + (o + nbp) * ld + o, ld, rows, ntrail, nbp, 0, 0, st);
+  }
+}
+
+// XT (rows x n, ld) <- XT * L^-1   (X <- L^-T X), block back substitution; rows multiple of 64
+void solve_bwd_enqueue(gpx_handle* h, double* XT, int64_t rows, const double* L, int64_t ld,
+                       int64_t n, int nb, const double* Winv) {
+  hipStream_t st = h->st;
+  int64_t last = ((n - 1) / nb) * nb;
+  for (int64_t o = last; o >= 0; o -= nb) {
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    launch_trsm_rln(XT + o, ld, rows, L + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, st);
+    if (o > 0) launch_gemm_nn(XT, ld, XT + o, ld, L + o * ld, ld, rows, o, nbp, st);
+  }
+}
+
+int copy_in(gpx_handle* h, void* dst, const void* src, size_t bytes, int mem_kind) {
+  if (bytes == 0) return GPX_OK;
+  HIPCHK(h, hipMemcpyAsync(dst, src, bytes,
+                           mem_kind == GPX_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                           h->st));
+  return GPX_OK;
+}
+
+int copy_out(gpx_handle* h, void* dst, const void* src, size_t bytes, int mem_kind) {
+  if (bytes == 0) return GPX_OK;
+  HIPCHK(h, hipMemcpyAsync(dst, src, bytes,
+                           mem_kind == GPX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                           h->st));
+  return GPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpx_abi_version(void) { return GPX_ABI_VERSION; }
+
+int gpx_device_count(int* count) {
+  if (!count) return GPX_E_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    *count = 0;
+    return GPX_E_HIP;
+  }
+  *count = n;
+  return GPX_OK;
+}
+
+const char* gpx_last_error(gpx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int gpx_create(gpx_handle** out, const gpx_config* cfg) {
+  if (!out || !cfg) return fail(nullptr, GPX_E_ARG, "gpx_create: null argument");
+  *out = nullptr;
+  if (cfg->kernel != GPX_KERNEL_RBF && cfg->kernel != GPX_KERNEL_MATERN52)
+    return fail(nullptr, GPX_E_ARG, "gpx_create: unknown kernel id");
+  if (cfg->dtype != GPX_F64)
+    return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: only GPX_F64 is implemented");
+  if (cfg->world != 1 || cfg->rank != 0)
+    return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: sharded (world > 1) handles not implemented yet");
+  const int nb = cfg->block == 0 ? 512 : cfg->block;
+  if (nb < 128 || nb > 1024 || nb % 128 != 0)
+    return fail(nullptr, GPX_E_ARG, "gpx_create: block must be a multiple of 128 in [128, 1024]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, GPX_E_HIP, "gpx_create: no HIP device visible (libgpx has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(nullptr, GPX_E_ARG, "gpx_create: device ordinal out of range");
+  gpx_handle* h = new (std::nothrow) gpx_handle();
+  if (!h) return fail(nullptr, GPX_E_NOMEM, "gpx_create: out of host memory");
+  h->cfg = *cfg;
+  h->nb = nb;
+  if (hipSetDevice(cfg->device) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return fail(nullptr, GPX_E_HIP, "gpx_create: hipSetDevice/hipStreamCreate failed");
+  }
+  *out = h;
+  return GPX_OK;
+}
+
+void gpx_destroy(gpx_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->st) (void)hipStreamSynchronize(h->st);
+  for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
+                    &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout})
+    release(*b);
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->st) (void)hipStreamDestroy(h->st);
+  delete h;
+}
+
+int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
+            const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter,
+            int32_t mem_kind, int64_t* info) {
+  if (!h) return GPX_E_ARG;
+  if (!X || !y || !lengthscale || !info) return fail(h, GPX_E_ARG, "gpx_fit: null argument");
+  if (N <= 0 || d <= 0 || d > 32) return fail(h, GPX_E_ARG, "gpx_fit: need N > 0 and 1 <= d <= 32");
+  if (k <= 0 || k > RHS_ROWS) return fail(h, GPX_E_ARG, "gpx_fit: need 1 <= k <= 64 target columns");
+  if (n_ls != 1 && n_ls != d) return fail(h, GPX_E_ARG, "gpx_fit: n_ls must be 1 or d");
+  if (mem_kind != GPX_MEM_HOST && mem_kind != GPX_MEM_DEVICE)
+    return fail(h, GPX_E_ARG, "gpx_fit: bad mem_kind");
+  if (!(sf2 > 0.0) || sn2 < 0.0 || jitter < 0.0)
+    return fail(h, GPX_E_ARG, "gpx_fit: need sf2 > 0, sn2 >= 0, jitter >= 0");
+  for (int i = 0; i < n_ls; ++i)
+    if (!(lengthscale[i] > 0.0)) return fail(h, GPX_E_ARG, "gpx_fit: lengthscale must be > 0");
+  if (N > (int64_t)INT_MAX - 4096) return fail(h, GPX_E_ARG, "gpx_fit: N too large");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  h->fitted = false;
+  h->err.clear();
+
+  const int64_t Npad = round_up(N, TILE);
+  const int64_t ld = Npad + LD_SKEW;
+  const int64_t ldp = h->nb + LD_SKEW;
+  h->N = N; h->Npad = Npad; h->ld = ld; h->ldp = ldp; h->d = d; h->k = k; h->n_ls = n_ls;
+  h->sf2 = sf2; h->sn2 = sn2; h->jitter = jitter;
+  const bool profile = (h->cfg.flags & GPX_FLAG_PROFILE) != 0;
+  gpx_timings& tm = h->tm;
+  tm.h2d = tm.kbuild = tm.chol = tm.solve = tm.logdet = tm.fit_total = 0;
+  tm.chol_diag = tm.chol_trsm = tm.chol_syrk = tm.syrk_flops = tm.comm = 0;
+  tm.syrk_launches = 0;
+  tm.kbuild_bytes = 8.0 * ((double)N * (double)(N + 1) / 2.0 + (double)N * d);
+
+  int rc;
+  if ((rc = ensure(h, h->X, (size_t)N * d * 8))) return rc;
+  if ((rc = ensure(h, h->Y, (size_t)N * k * 8))) return rc;
+  if ((rc = ensure(h, h->Xs, (size_t)Npad * d * 8))) return rc;
+  if ((rc = ensure(h, h->ls, 32 * 8))) return rc;
+  if ((rc = ensure(h, h->K, (size_t)Npad * ld * 8))) return rc;
+  if ((rc = ensure(h, h->Winv, (size_t)(Npad / KB) * KB * KB * 8))) return rc;
+  if ((rc = ensure(h, h->P, (size_t)Npad * ldp * 8))) return rc;
+  if ((rc = ensure(h, h->YT, (size_t)RHS_ROWS * ld * 8))) return rc;
+  if ((rc = ensure(h, h->scalars, 64))) return rc;
+  if ((rc = ensure(h, h->info, 64))) return rc;
+
+  double* dK = (double*)h->K.p;
+  double* dYT = (double*)h->YT.p;
+  int* dInfo = (int*)h->info.p;
+  {
+    PhaseScope total(h, &tm.fit_total);
+    {
+      PhaseScope ps(h, &tm.h2d);
+      if ((rc = copy_in(h, h->X.p, X, (size_t)N * d * 8, mem_kind))) return rc;
+      if ((rc = copy_in(h, h->Y.p, y, (size_t)N * k * 8, mem_kind))) return rc;
+      if ((rc = copy_in(h, h->ls.p, lengthscale, (size_t)n_ls * 8, GPX_MEM_HOST))) return rc;
+      const int init = INT_MAX;
+      HIPCHK(h, hipMemcpyAsync(dInfo, &init, sizeof(int), hipMemcpyHostToDevice, h->st));
+    }
+    {
+      PhaseScope ps(h, &tm.kbuild);
+      launch_scale_points((const double*)h->X.p, N, Npad, d, (const double*)h->ls.p, n_ls,
+                          (double*)h->Xs.p, h->st);
+      launch_kbuild_sym(h->cfg.kernel, (const double*)h->Xs.p, N, Npad, d, sf2, sn2 + jitter, dK, ld,
+                        h->st);
+    }
+    {
+      PhaseScope ps(h, &tm.chol);
+      chol_enqueue(h, dK, ld, Npad, h->nb, (double*)h->Winv.p, (double*)h->P.p, ldp, dInfo, 0,
+                   profile);
+    }
+    {
+      PhaseScope ps(h, &tm.solve);
+      launch_pack_rhs((const double*)h->Y.p, N, k, dYT, ld, Npad, RHS_ROWS, h->st);
+      solve_fwd_enqueue(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb, (const double*)h->Winv.p);
+      solve_bwd_enqueue(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb, (const double*)h->Winv.p);
+    }
+    {
+      PhaseScope ps(h, &tm.logdet);
+      launch_logdet(dK, ld, Npad, (double*)h->scalars.p, h->st);
+    }
+  }
+  int hinfo = 0;
+  HIPCHK(h, hipMemcpyAsync(&hinfo, dInfo, sizeof(int), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipMemcpyAsync(&h->logdet, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  HIPCHK(h, hipGetLastError());
+  collect_phases(h);
+  *info = (hinfo == INT_MAX) ? 0 : (int64_t)hinfo;
+  h->fitted = (*info == 0);
+  return GPX_OK;
+}
+
+int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var, int32_t mem_kind) {
+  if (!h) return GPX_E_ARG;
+  if (!h->fitted) return fail(h, GPX_E_ARG, "gpx_predict: handle has no successful fit");
+  if (!Xq || !mean || M <= 0) return fail(h, GPX_E_ARG, "gpx_predict: bad argument");
+  if (mem_kind != GPX_MEM_HOST && mem_kind != GPX_MEM_DEVICE)
+    return fail(h, GPX_E_ARG, "gpx_predict: bad mem_kind");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  h->err.clear();
+  const int64_t N = h->N, Npad = h->Npad, ld = h->ld;
+  const int d = h->d, k = h->k;
+  const int64_t Mpad = round_up(M, TILE);
+  const int64_t ldm = Mpad + LD_SKEW;
+  gpx_timings& tm = h->tm;
+  tm.kstar = tm.mean = tm.trsm = tm.var = tm.d2h = tm.predict_total = 0;
+
+  int rc;
+  if ((rc = ensure(h, h->Q, (size_t)M * d * 8))) return rc;
+  if ((rc = ensure(h, h->Qs, (size_t)Mpad * d * 8))) return rc;
+  if ((rc = ensure(h, h->VT, (size_t)Mpad * ld * 8))) return rc;
+  if ((rc = ensure(h, h->MT, (size_t)RHS_ROWS * ldm * 8))) return rc;
+  if ((rc = ensure(h, h->meanout, (size_t)M * k * 8))) return rc;
+  if ((rc = ensure(h, h->var, (size_t)Mpad * 8))) return rc;
+  double* dVT = (double*)h->VT.p;
+  const double* dK = (const double*)h->K.p;
+  const double* dWinv = (const double*)h->Winv.p;
+  {
+    PhaseScope total(h, &tm.predict_total);
+    {
+      PhaseScope ps(h, &tm.kstar);
+      if ((rc = copy_in(h, h->Q.p, Xq, (size_t)M * d * 8, mem_kind))) return rc;
+      launch_scale_points((const double*)h->Q.p, M, Mpad, d, (const double*)h->ls.p, h->n_ls,
+                          (double*)h->Qs.p, h->st);
+      launch_kbuild_cross(h->cfg.kernel, (const double*)h->Qs.p, M, Mpad, (const double*)h->Xs.p, N,
+                          Npad, d, h->sf2, dVT, ld, h->st);
+    }
+    {
+      // mean^T (64 x Mpad) = alpha^T (64 x Npad) * K*^T
+      PhaseScope ps(h, &tm.mean);
+      launch_gemm_nt(64, (double*)h->MT.p, ldm, (const double*)h->YT.p, ld, dVT, ld, RHS_ROWS, Mpad,
+                     Npad, 0, 1, h->st);
+      launch_unpack_rhs((const double*)h->MT.p, ldm, M, k, 1.0, (double*)h->meanout.p, h->st);
+    }
+    if (var) {
+      {
+        PhaseScope ps(h, &tm.trsm);
+        solve_fwd_enqueue(h, dVT, Mpad, dK, ld, Npad, h->nb, dWinv);
+      }
+      {
+        PhaseScope ps(h, &tm.var);
+        launch_var_rows(dVT, ld, M, Npad, h->sf2, (double*)h->var.p, h->st);
+      }
+    }
+    {
+      PhaseScope ps(h, &tm.d2h);
+      if ((rc = copy_out(h, mean, h->meanout.p, (size_t)M * k * 8, mem_kind))) return rc;
+      if (var && (rc = copy_out(h, var, h->var.p, (size_t)M * 8, mem_kind))) return rc;
+    }
+  }
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  HIPCHK(h, hipGetLastError());
+  collect_phases(h);
+  return GPX_OK;
+}
+
+int gpx_get_alpha(gpx_handle* h, void* out) {
+  if (!h) return GPX_E_ARG;
+  if (!h->fitted || !out) return fail(h, GPX_E_ARG, "gpx_get_alpha: no fit or null output");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  int rc;
+  if ((rc = ensure(h, h->meanout, (size_t)h->N * h->k * 8))) return rc;
+  launch_unpack_rhs((const double*)h->YT.p, h->ld, h->N, h->k, 1.0, (double*)h->meanout.p, h->st);
+  HIPCHK(h, hipMemcpyAsync(out, h->meanout.p, (size_t)h->N * h->k * 8, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return GPX_OK;
+}
+
+int gpx_logdet(gpx_handle* h, double* out) {
+  if (!h) return GPX_E_ARG;
+  if (!h->fitted || !out) return fail(h, GPX_E_ARG, "gpx_logdet: no fit or null output");
+  *out = h->logdet;
+  return GPX_OK;
+}
+
+int gpx_get_timings(gpx_handle* h, gpx_timings* out) {
+  if (!h || !out) return GPX_E_ARG;
+  *out = h->tm;
+  return GPX_OK;
+}
+
+int gpx_comm_unique_id(void* id128) {
+  (void)id128;
+  return GPX_E_UNSUPPORTED;
+}
+
+int gpx_comm_init(gpx_handle* h, const void* id128) {
+  (void)id128;
+  return fail(h, GPX_E_UNSUPPORTED, "gpx_comm_init: sharded handles not implemented yet");
+}
+
+// ---- kernel unit-test entry points -------------------------------------------------------
+namespace {
+struct Scratch {  // a throw-away handle-like context for the host-buffer entry points
+  gpx_handle h;
+  bool ok = false;
+  Scratch() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    h.cfg.device = dev;
+    ok = hipStreamCreateWithFlags(&h.st, hipStreamNonBlocking) == hipSuccess;
+  }
+  ~Scratch() {
+    if (h.st) {
+      (void)hipStreamSynchronize(h.st);
+      (void)hipStreamDestroy(h.st);
+    }
+    for (auto e : h.ev_pool) (void)hipEventDestroy(e);
+  }
+};
+#define TCHK(call)                                   \
+  do {                                               \
+    if ((call) != hipSuccess) {                      \
+      g_create_error = #call " failed";             \
+      rc = GPX_E_HIP;                                \
+      goto done;                                     \
+    }                                                \
+  } while (0)
+}  // namespace
+
+int gpx_kernel_matrix(int32_t kernel, const double* A, int64_t na, const double* B, int64_t nb_,
+                      int32_t d, const double* lengthscale, int32_t n_ls, double sf2,
+                      double diag_add, double* K) {
+  if (!A || !K || !lengthscale || na <= 0 || d <= 0 || d > 32 || (n_ls != 1 && n_ls != d))
+    return GPX_E_ARG;
+  if (kernel != GPX_KERNEL_RBF && kernel != GPX_KERNEL_MATERN52) return GPX_E_ARG;
+  const bool sym = (B == nullptr);
+  const int64_t nbb = sym ? na : nb_;
+  if (nbb <= 0) return GPX_E_ARG;
+  Scratch sc;
+  if (!sc.ok) return GPX_E_HIP;
+  hipStream_t st = sc.h.st;
+  const int64_t napad = round_up(na, 64), nbpad = round_up(nbb, 64), ld = nbpad;
+  double *dA = nullptr, *dB = nullptr, *dAs = nullptr, *dBs = nullptr, *dls = nullptr, *dK = nullptr;
+  std::vector<double> host((size_t)napad * ld);
+  int rc = GPX_OK;
+  TCHK(hipMalloc(&dA, (size_t)na * d * 8));
+  TCHK(hipMalloc(&dAs, (size_t)napad * d * 8));
+  TCHK(hipMalloc(&dls, 32 * 8));
+  TCHK(hipMalloc(&dK, (size_t)napad * ld * 8));
+  TCHK(hipMemcpyAsync(dA, A, (size_t)na * d * 8, hipMemcpyHostToDevice, st));
+  TCHK(hipMemcpyAsync(dls, lengthscale, (size_t)n_ls * 8, hipMemcpyHostToDevice, st));
+  TCHK(hipMemsetAsync(dK, 0, (size_t)napad * ld * 8, st));
+  launch_scale_points(dA, na, napad, d, dls, n_ls, dAs, st);
+  if (sym) {
+    launch_kbuild_sym(kernel, dAs, na, napad, d, sf2, diag_add, dK, ld, st);
+  } else {
+    TCHK(hipMalloc(&dB, (size_t)nbb * d * 8));
+    TCHK(hipMalloc(&dBs, (size_t)nbpad * d * 8));
+    TCHK(hipMemcpyAsync(dB, B, (size_t)nbb * d * 8, hipMemcpyHostToDevice, st));
+    launch_scale_points(dB, nbb, nbpad, d, dls, n_ls, dBs, st);
+    launch_kbuild_cross(kernel, dAs, na, napad, dBs, nbb, nbpad, d, sf2, dK, ld, st);
+  }
+  TCHK(hipMemcpyAsync(host.data(), dK, (size_t)napad * ld * 8, hipMemcpyDeviceToHost, st));
+  TCHK(hipStreamSynchronize(st));
+  TCHK(hipGetLastError());
+  for (int64_t i = 0; i < na; ++i)
+    memcpy(K + i * nbb, host.data() + i * ld, (size_t)nbb * 8);  // sym: upper part is zero (not built)
+done:
+  for (double* p : {dA, dB, dAs, dBs, dls, dK})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info) {
+  if (!A || !info || n <= 0 || n % 64 != 0) return GPX_E_ARG;
+  const int nb = block == 0 ? 512 : block;
+  if (nb % 128 != 0 || nb < 128) return GPX_E_ARG;
+  Scratch sc;
+  if (!sc.ok) return GPX_E_HIP;
+  hipStream_t st = sc.h.st;
+  const int64_t ld = n + LD_SKEW, ldp = nb + LD_SKEW;
+  double *dA = nullptr, *dW = nullptr, *dP = nullptr;
+  int* dInfo = nullptr;
+  int hinfo = INT_MAX;
+  int rc = GPX_OK;
+  TCHK(hipMalloc(&dA, (size_t)n * ld * 8));
+  TCHK(hipMalloc(&dW, (size_t)(n / 64) * 4096 * 8));
+  TCHK(hipMalloc(&dP, (size_t)n * ldp * 8));
+  TCHK(hipMalloc(&dInfo, 64));
+  TCHK(hipMemcpy2DAsync(dA, (size_t)ld * 8, A, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice, st));
+  TCHK(hipMemcpyAsync(dInfo, &hinfo, sizeof(int), hipMemcpyHostToDevice, st));
+  chol_enqueue(&sc.h, dA, ld, n, nb, dW, dP, ldp, dInfo, 0, false);
+  TCHK(hipMemcpy2DAsync(A, (size_t)n * 8, dA, (size_t)ld * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost, st));
+  TCHK(hipMemcpyAsync(&hinfo, dInfo, sizeof(int), hipMemcpyDeviceToHost, st));
+  TCHK(hipStreamSynchronize(st));
+  TCHK(hipGetLastError());
+  *info = (hinfo == INT_MAX) ? 0 : hinfo;
+done:
+  for (void* p : {(void*)dA, (void*)dW, (void*)dP, (void*)dInfo})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+int gpx_trsm(double* X, int64_t m, const double* L, int64_t nb) {
+  if (!X || !L || m <= 0 || nb <= 0 || m % 64 != 0 || nb % 64 != 0) return GPX_E_ARG;
+  Scratch sc;
+  if (!sc.ok) return GPX_E_HIP;
+  hipStream_t st = sc.h.st;
+  const int64_t ldx = nb + LD_SKEW, ldl = nb + LD_SKEW;
+  double *dX = nullptr, *dL = nullptr, *dL2 = nullptr, *dW = nullptr;
+  int* dInfo = nullptr;
+  int hinfo = INT_MAX;
+  int rc = GPX_OK;
+  TCHK(hipMalloc(&dX, (size_t)m * ldx * 8));
+  TCHK(hipMalloc(&dL, (size_t)nb * ldl * 8));
+  TCHK(hipMalloc(&dL2, (size_t)nb * ldl * 8));
+  TCHK(hipMalloc(&dW, (size_t)(nb / 64) * 4096 * 8));
+  TCHK(hipMalloc(&dInfo, 64));
+  TCHK(hipMemcpy2DAsync(dX, (size_t)ldx * 8, X, (size_t)nb * 8, (size_t)nb * 8, (size_t)m, hipMemcpyHostToDevice, st));
+  TCHK(hipMemcpy2DAsync(dL, (size_t)ldl * 8, L, (size_t)nb * 8, (size_t)nb * 8, (size_t)nb, hipMemcpyHostToDevice, st));
+  TCHK(hipMemcpyAsync(dInfo, &hinfo, sizeof(int), hipMemcpyHostToDevice, st));
+  // inverse diagonal blocks of the GIVEN factor: potf2 of (L_qq L_qq^T) reproduces L_qq up to
+  // rounding, so build them from a scratch copy of the products instead.
+  {
+    std::vector<double> G((size_t)nb / 64 * 4096);
+    for (int64_t q = 0; q < nb / 64; ++q)
+      for (int i = 0; i < 64; ++i)
+        for (int j = 0; j < 64; ++j) {
+          double s = 0.0;
+          for (int t = 0; t <= std::min(i, j); ++t)
+            s += L[(q * 64 + i) * nb + q * 64 + t] * L[(q * 64 + j) * nb + q * 64 + t];
+          G[(size_t)q * 4096 + i * 64 + j] = s;
+        }
+    TCHK(hipMemcpyAsync(dL2, G.data(), G.size() * 8, hipMemcpyHostToDevice, st));
+    TCHK(hipStreamSynchronize(st));
+  }
+  for (int64_t q = 0; q < nb / 64; ++q)
+    launch_potf2_64(dL2 + q * 4096, 64, dW + q * 4096, q * 64, dInfo, st);
+  launch_trsm_rlt(dX, ldx, m, dL, ldl, dW, (int)nb, nullptr, 0, st);
+  TCHK(hipMemcpy2DAsync(X, (size_t)nb * 8, dX, (size_t)ldx * 8, (size_t)nb * 8, (size_t)m, hipMemcpyDeviceToHost, st));
+  TCHK(hipStreamSynchronize(st));
+  TCHK(hipGetLastError());
+done:
+  for (void* p : {(void*)dX, (void*)dL, (void*)dL2, (void*)dW, (void*)dInfo})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+int gpx_gemm_nt(double* C, int64_t m, int64_t n, const double* A, const double* B, int64_t k,
+                int32_t lower) {
+  if (!C || !A || !B || m <= 0 || n <= 0 || k <= 0 || m % 64 || n % 64 || k % 16) return GPX_E_ARG;
+  if (lower && m != n) return GPX_E_ARG;
+  Scratch sc;
+  if (!sc.ok) return GPX_E_HIP;
+  hipStream_t st = sc.h.st;
+  const int64_t ldc = n + LD_SKEW, lda = k + LD_SKEW;
+  const int tile = (m % 128 == 0 && n % 128 == 0) ? 128 : 64;
+  double *dC = nullptr, *dA = nullptr, *dB = nullptr;
+  int rc = GPX_OK;
+  TCHK(hipMalloc(&dC, (size_t)m * ldc * 8));
+  TCHK(hipMalloc(&dA, (size_t)m * lda * 8));
+  TCHK(hipMalloc(&dB, (size_t)n * lda * 8));
+  TCHK(hipMemcpy2DAsync(dC, (size_t)ldc * 8, C, (size_t)n * 8, (size_t)n * 8, (size_t)m, hipMemcpyHostToDevice, st));
+  TCHK(hipMemcpy2DAsync(dA, (size_t)lda * 8, A, (size_t)k * 8, (size_t)k * 8, (size_t)m, hipMemcpyHostToDevice, st));
+  TCHK(hipMemcpy2DAsync(dB, (size_t)lda * 8, B, (size_t)k * 8, (size_t)k * 8, (size_t)n, hipMemcpyHostToDevice, st));
+  launch_gemm_nt(tile, dC, ldc, dA, lda, dB, lda, m, n, k, lower, 0, st);
+  TCHK(hipMemcpy2DAsync(C, (size_t)n * 8, dC, (size_t)ldc * 8, (size_t)n * 8, (size_t)m, hipMemcpyDeviceToHost, st));
+  TCHK(hipStreamSynchronize(st));
+  TCHK(hipGetLastError());
+done:
+  for (double* p : {dC, dA, dB})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+int gpx_mfma_probe(const double* A, const double* B, double* D) {
+  if (!A || !B || !D) return GPX_E_ARG;
+  Scratch sc;
+  if (!sc.ok) return GPX_E_HIP;
+  hipStream_t st = sc.h.st;
+  double* d = nullptr;
+  int rc = GPX_OK;
+  TCHK(hipMalloc(&d, (64 + 64 + 256) * 8));
+  TCHK(hipMemcpyAsync(d, A, 64 * 8, hipMemcpyHostToDevice, st));
+  TCHK(hipMemcpyAsync(d + 64, B, 64 * 8, hipMemcpyHostToDevice, st));
+  launch_mfma_probe(d, d + 64, d + 128, st);
+  TCHK(hipMemcpyAsync(D, d + 128, 256 * 8, hipMemcpyDeviceToHost, st));
+  TCHK(hipStreamSynchronize(st));
+  TCHK(hipGetLastError());
+done:
+  if (d) (void)hipFree(d);
+  return rc;
+}
+
+int gpx_microbench(double* mfma_tflops, double* copy_gbs) {
+  if (!mfma_tflops || !copy_gbs) return GPX_E_ARG;
+  Scratch sc;
+  if (!sc.ok) return GPX_E_HIP;
+  hipStream_t st = sc.h.st;
+  double *sink = nullptr, *src = nullptr, *dst = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const int64_t count = (int64_t)1 << 28;  // 2 GiB per buffer
+  const int iters = 4096, blocks = 256 * 8;
+  float ms = 0.f;
+  int rc = GPX_OK;
+  TCHK(hipMalloc(&sink, 64));
+  TCHK(hipMalloc(&src, (size_t)count * 8));
+  TCHK(hipMalloc(&dst, (size_t)count * 8));
+  TCHK(hipEventCreate(&e0));
+  TCHK(hipEventCreate(&e1));
+  TCHK(hipMemsetAsync(src, 0x11, (size_t)count * 8, st));
+  launch_mfma_loop(sink, 64, blocks, st);  // warm-up
+  TCHK(hipEventRecord(e0, st));
+  launch_mfma_loop(sink, iters, blocks, st);
+  TCHK(hipEventRecord(e1, st));
+  TCHK(hipEventSynchronize(e1));
+  TCHK(hipEventElapsedTime(&ms, e0, e1));
+  *mfma_tflops = (double)blocks * 4 * (double)iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
+  launch_copy(src, dst, count, st);  // warm-up
+  TCHK(hipEventRecord(e0, st));
+  for (int r = 0; r < 5; ++r) launch_copy(src, dst, count, st);
+  TCHK(hipEventRecord(e1, st));
+  TCHK(hipEventSynchronize(e1));
+  TCHK(hipEventElapsedTime(&ms, e0, e1));
+  *copy_gbs = 5.0 * 2.0 * (double)count * 8.0 / (ms * 1e-3) / 1e9;
+  TCHK(hipGetLastError());
+done:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  for (double* p : {sink, src, dst})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+}  // extern "C"

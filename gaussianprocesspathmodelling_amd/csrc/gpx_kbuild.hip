@@ -1,0 +1,165 @@
+// gpx_kbuild.hip — kernel-matrix builder (SURVEY.md §8 rows a1 "K1" and a2 "K1'").
+//
+// The reference has no kernel-matrix code; its nearest relative is the pairwise
+// distance loop trajectories.calc_distance (GPmap.py:114-121).  Formula and
+// operation order follow oracle/gp_oracle.py:kernel_matrix.
+//
+// HBM-write-bound: one 64x64 tile of K per 256-thread workgroup, input points staged
+// once in LDS, each lane writes 16-byte (2 x f64) pieces so a half-wave covers 512
+// contiguous bytes of one row.  Algorithmic traffic: 8 B per entry written, the
+// points (N*d*8 B) read once per tile row/column from L2.
+#include "gpx_internal.h"
+
+namespace gpx {
+namespace {
+
+constexpr int KT = 64;      // tile edge
+constexpr int MAXD = 32;    // max input dimension staged in LDS
+constexpr double SQRT5 = 2.23606797749978969640917366873128;
+
+template <int KERNEL>
+__device__ __forceinline__ double kfun(double r2, double sf2) {
+  if (KERNEL == 0) {
+    return sf2 * exp(-0.5 * r2);
+  } else {
+    const double s = SQRT5 * sqrt(r2);
+    return sf2 * ((1.0 + s + s * s / 3.0) * exp(-s));
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_points_kernel(const double* __restrict__ X, int64_t n,
+                                                          int64_t npad, int d,
+                                                          const double* __restrict__ ls, int n_ls,
+                                                          double* __restrict__ Xs) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npad * d) return;
+  const int64_t i = idx / d;
+  const int c = (int)(idx - i * d);
+  Xs[idx] = (i < n) ? X[idx] / ls[n_ls == 1 ? 0 : c] : 0.0;
+}
+
+// linear index over the lower triangle (row-major) -> (ti, tj), tj <= ti
+__device__ __forceinline__ void tri_coords(int64_t t, int& ti, int& tj) {
+  int64_t i = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (i * (i + 1) / 2 > t) --i;
+  while ((i + 1) * (i + 2) / 2 <= t) ++i;
+  ti = (int)i;
+  tj = (int)(t - i * (i + 1) / 2);
+}
+
+// SYM: lower tiles of a square matrix built from one point set (As == Bs), diagonal
+// gets + diag_add, padding becomes identity.  !SYM: all tiles, padding is zero.
+template <int KERNEL, bool SYM, int D>
+__global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ As, int64_t m,
+                                                    const double* __restrict__ Bs, int64_t n,
+                                                    int d_rt, int tiles_n, double sf2,
+                                                    double diag_add, double* __restrict__ K,
+                                                    int64_t ld) {
+  const int d = (D > 0) ? D : d_rt;
+  __shared__ double xa[KT * MAXD];
+  __shared__ double xb[KT * MAXD];
+  int ti, tj;
+  if (SYM) {
+    tri_coords((int64_t)blockIdx.x, ti, tj);
+  } else {
+    ti = (int)(blockIdx.x / tiles_n);
+    tj = (int)(blockIdx.x - (int64_t)ti * tiles_n);
+  }
+  const int64_t i0 = (int64_t)ti * KT, j0 = (int64_t)tj * KT;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < KT * d; e += 256) {
+    xa[e] = As[i0 * d + e];  // rows of the padded point array are always readable
+    xb[e] = Bs[j0 * d + e];
+  }
+  __syncthreads();
+  const int c2 = (tid & 31) * 2;
+  const int rg = tid >> 5;
+  double bj0[D > 0 ? D : MAXD], bj1[D > 0 ? D : MAXD];
+  if (D > 0) {
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      bj0[c] = xb[c2 * D + c];
+      bj1[c] = xb[(c2 + 1) * D + c];
+    }
+  }
+  const int64_t col0 = j0 + c2, col1 = col0 + 1;
+#pragma unroll 2
+  for (int r = 0; r < 8; ++r) {
+    const int il = rg + 8 * r;
+    const int64_t row = i0 + il;
+    double s0 = 0.0, s1 = 0.0;
+    if (D > 0) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        const double a = xa[il * D + c];
+        const double e0 = a - bj0[c], e1 = a - bj1[c];
+        s0 += e0 * e0;
+        s1 += e1 * e1;
+      }
+    } else {
+      for (int c = 0; c < d; ++c) {
+        const double a = xa[il * d + c];
+        const double e0 = a - xb[c2 * d + c], e1 = a - xb[(c2 + 1) * d + c];
+        s0 += e0 * e0;
+        s1 += e1 * e1;
+      }
+    }
+    double v0 = kfun<KERNEL>(s0, sf2), v1 = kfun<KERNEL>(s1, sf2);
+    if (SYM) {
+      if (row == col0) v0 += diag_add;
+      if (row == col1) v1 += diag_add;
+      if (row >= m || col0 >= n) v0 = (row == col0) ? 1.0 : 0.0;
+      if (row >= m || col1 >= n) v1 = (row == col1) ? 1.0 : 0.0;
+    } else {
+      if (row >= m || col0 >= n) v0 = 0.0;
+      if (row >= m || col1 >= n) v1 = 0.0;
+    }
+    double2 out;
+    out.x = v0;
+    out.y = v1;
+    *reinterpret_cast<double2*>(K + row * ld + col0) = out;
+  }
+}
+
+template <int KERNEL, bool SYM>
+void dispatch_d(const double* As, int64_t m, const double* Bs, int64_t n, int d, int64_t nblocks,
+                int tiles_n, double sf2, double diag_add, double* K, int64_t ld, hipStream_t st) {
+  dim3 grid((unsigned)nblocks), block(256);
+  switch (d) {
+    case 1: hipLaunchKernelGGL((kbuild_kernel<KERNEL, SYM, 1>), grid, block, 0, st, As, m, Bs, n, d, tiles_n, sf2, diag_add, K, ld); break;
+    case 2: hipLaunchKernelGGL((kbuild_kernel<KERNEL, SYM, 2>), grid, block, 0, st, As, m, Bs, n, d, tiles_n, sf2, diag_add, K, ld); break;
+    case 3: hipLaunchKernelGGL((kbuild_kernel<KERNEL, SYM, 3>), grid, block, 0, st, As, m, Bs, n, d, tiles_n, sf2, diag_add, K, ld); break;
+    default: hipLaunchKernelGGL((kbuild_kernel<KERNEL, SYM, 0>), grid, block, 0, st, As, m, Bs, n, d, tiles_n, sf2, diag_add, K, ld); break;
+  }
+}
+
+}  // namespace
+
+void launch_scale_points(const double* X, int64_t n, int64_t npad, int d, const double* ls,
+                         int n_ls, double* Xs, hipStream_t st) {
+  const int64_t total = npad * d;
+  hipLaunchKernelGGL(scale_points_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     X, n, npad, d, ls, n_ls, Xs);
+}
+
+void launch_kbuild_sym(int kernel, const double* Xs, int64_t n, int64_t npad, int d, double sf2,
+                       double diag_add, double* K, int64_t ld, hipStream_t st) {
+  const int64_t T = npad / KT;
+  const int64_t nblocks = T * (T + 1) / 2;
+  if (kernel == 0)
+    dispatch_d<0, true>(Xs, n, Xs, n, d, nblocks, (int)T, sf2, diag_add, K, ld, st);
+  else
+    dispatch_d<1, true>(Xs, n, Xs, n, d, nblocks, (int)T, sf2, diag_add, K, ld, st);
+}
+
+void launch_kbuild_cross(int kernel, const double* As, int64_t m, int64_t mpad, const double* Bs,
+                         int64_t n, int64_t npad, int d, double sf2, double* K, int64_t ld,
+                         hipStream_t st) {
+  const int64_t tm = mpad / KT, tn = npad / KT;
+  if (kernel == 0)
+    dispatch_d<0, false>(As, m, Bs, n, d, tm * tn, (int)tn, sf2, 0.0, K, ld, st);
+  else
+    dispatch_d<1, false>(As, m, Bs, n, d, tm * tn, (int)tn, sf2, 0.0, K, ld, st);
+}
+
+}  // namespace gpx

@@ -1,0 +1,151 @@
+// gpx_misc.hip — small HBM-bound helpers around the dense path: right-hand-side
+// packing, posterior variance row reduction (SURVEY.md §8 row a6 "K4"), log-det,
+// plus the fp64 MFMA layout probe and the two microbenchmarks quoted beside the
+// rooflines.
+#include "gpx_internal.h"
+
+namespace gpx {
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void fill_kernel(double* p, int64_t count, double v) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    p[i] = v;
+}
+
+// YT[r][i] = (r < k && i < n) ? y[i*k + r] : 0
+__global__ __launch_bounds__(256) void pack_rhs_kernel(const double* __restrict__ y, int64_t n, int k,
+                                                      double* __restrict__ YT, int64_t ld,
+                                                      int64_t npad) {
+  const int r = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npad; i += (int64_t)gridDim.x * 256)
+    YT[(int64_t)r * ld + i] = (r < k && i < n) ? y[i * k + r] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void unpack_rhs_kernel(const double* __restrict__ YT, int64_t ld,
+                                                        int64_t n, int k, double scale,
+                                                        double* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * k) return;
+  const int64_t i = idx / k;
+  const int r = (int)(idx - i * k);
+  out[idx] = scale * YT[(int64_t)r * ld + i];
+}
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  const double s = ((red[0] + red[1]) + (red[2] + red[3]));
+  __syncthreads();
+  return s;
+}
+
+// one workgroup per row: var[i] = sf2 - sum_j VT[i][j]^2  (fixed summation order)
+__global__ __launch_bounds__(256) void var_rows_kernel(const double* __restrict__ VT, int64_t ld,
+                                                      int64_t ncols, double sf2,
+                                                      double* __restrict__ var) {
+  __shared__ double red[4];
+  const double* row = VT + (int64_t)blockIdx.x * ld;
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t j = (int64_t)threadIdx.x * 2; j < ncols; j += 512) {
+    const double2 v = *reinterpret_cast<const double2*>(row + j);
+    s0 += v.x * v.x;
+    s1 += v.y * v.y;
+  }
+  const double s = block_sum(s0 + s1, red);
+  if (threadIdx.x == 0) var[blockIdx.x] = sf2 - s;
+}
+
+__global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ A, int64_t lda,
+                                                    int64_t n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += log(A[i * lda + i]);
+  const double t = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = 2.0 * t;
+}
+
+// D(16x16) = A(16x4) * B(4x16) through one v_mfma_f64_16x16x4_f64
+__global__ __launch_bounds__(64) void mfma_probe_kernel(const double* A, const double* B, double* D) {
+  const int l = threadIdx.x;
+  const double a = A[(l & 15) * 4 + (l >> 4)];
+  const double b = B[(l >> 4) * 16 + (l & 15)];
+  v4d c = {0.0, 0.0, 0.0, 0.0};
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = c[r];
+}
+
+// register-resident fp64 MFMA loop: 16 independent accumulators per wave
+__global__ __launch_bounds__(256) void mfma_loop_kernel(double* sink, int iters) {
+  const int l = threadIdx.x;
+  double a = 1.0 + 1e-9 * l, b = 1.0 - 1e-9 * l;
+  v4d acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) sink[0] = s;  // keep the loop alive
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const double2* __restrict__ src,
+                                                  double2* __restrict__ dst, int64_t count2) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count2;
+       i += (int64_t)gridDim.x * 256)
+    dst[i] = src[i];
+}
+
+}  // namespace
+
+void launch_fill(double* p, int64_t count, double v, hipStream_t st) {
+  if (count <= 0) return;
+  const int64_t blocks = (count + 255) / 256;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, p, count, v);
+}
+
+void launch_pack_rhs(const double* y, int64_t n, int k, double* YT, int64_t ld, int64_t npad, int R,
+                     hipStream_t st) {
+  const int64_t bx = (npad + 255) / 256;
+  hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, y, n, k, YT, ld, npad);
+}
+
+void launch_unpack_rhs(const double* YT, int64_t ld, int64_t n, int k, double scale, double* out,
+                       hipStream_t st) {
+  const int64_t total = n * k;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(unpack_rhs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, YT, ld, n, k, scale, out);
+}
+
+void launch_var_rows(const double* VT, int64_t ld, int64_t m, int64_t ncols, double sf2, double* var,
+                     hipStream_t st) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(var_rows_kernel, dim3((unsigned)m), dim3(256), 0, st, VT, ld, ncols, sf2, var);
+}
+
+void launch_logdet(const double* A, int64_t lda, int64_t n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, st, A, lda, n, out);
+}
+
+void launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, st, A, B, D);
+}
+
+void launch_mfma_loop(double* sink, int iters, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_loop_kernel, dim3((unsigned)blocks), dim3(256), 0, st, sink, iters);
+}
+
+void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st) {
+  hipLaunchKernelGGL(copy_kernel, dim3(4096), dim3(256), 0, st, reinterpret_cast<const double2*>(src),
+                     reinterpret_cast<double2*>(dst), count / 2);
+}
+
+}  // namespace gpx

@@ -1,0 +1,209 @@
+"""Exact Gaussian-process regression with a ``fit()`` / ``predict()`` surface.
+
+This is the Python host side of the hot path.  The upstream reference
+(``GPmap.py``) has no such class — its public names are ``trajectory``,
+``trajectories``, ``readcsvfile`` (``GPmap.py:12,28,178``) — so the surface is the one
+BASELINE.json's north_star names: hyper-parameters are fixed inputs, ``fit(X, y)``
+factorises ``K = sf2 k(X,X) + (sn2 + jitter) I`` and solves for ``alpha``,
+``predict(Xs)`` returns the posterior mean and (latent) variance.
+
+All arithmetic runs in ``csrc/libgpx.so`` (hand-written HIP for gfx950) through the
+ctypes C ABI of ``include/gpx.h``.  There is no CPU code path: without the library or
+without a GPU, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class GP:
+    """Exact GP regressor on one MI355X (or a row-block shard of several).
+
+    Parameters
+    ----------
+    kernel : "rbf" | "matern52"
+    lengthscale : float or array of d floats (ARD)
+    variance : signal variance sf2
+    noise : observation-noise variance sn2 (added to the diagonal)
+    jitter : extra diagonal term; default 1e-10 * variance
+    dtype : "float64" (implemented) | "float32"
+    device : HIP device ordinal (default: LOCAL_RANK or 0)
+    block : Cholesky panel width nb (multiple of 128; 0 = library default 512)
+    max_tries : jitter escalations (x10 each) before ``LinAlgError``
+    profile : record per-launch timings of the Cholesky sub-phases
+    """
+
+    def __init__(self, kernel="rbf", lengthscale=1.0, variance=1.0, noise=1e-2, jitter=None,
+                 dtype="float64", device=None, block=0, max_tries=3, profile=False):
+        if kernel not in _abi.KERNEL_IDS:
+            raise ValueError(f"unknown kernel {kernel!r}; expected one of {sorted(_abi.KERNEL_IDS)}")
+        if dtype not in _abi.DTYPE_IDS:
+            raise ValueError(f"unknown dtype {dtype!r}")
+        self.kernel = kernel
+        self.lengthscale = np.atleast_1d(np.asarray(lengthscale, dtype=np.float64)).copy()
+        if self.lengthscale.ndim != 1 or not np.all(self.lengthscale > 0):
+            raise ValueError("lengthscale must be a positive scalar or 1-D array")
+        self.variance = float(variance)
+        self.noise = float(noise)
+        if not self.variance > 0 or self.noise < 0:
+            raise ValueError("need variance > 0 and noise >= 0")
+        self.jitter = 1e-10 * self.variance if jitter is None else float(jitter)
+        self.dtype = dtype
+        self.block = int(block)
+        self.max_tries = int(max_tries)
+        if device is None:
+            import os
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = int(device)
+        self._lib = _abi.load()
+        cfg = _abi.GpxConfig(kernel=_abi.KERNEL_IDS[kernel], dtype=_abi.DTYPE_IDS[dtype],
+                             device=self.device, block=self.block, rank=0, world=1,
+                             flags=_abi.FLAG_PROFILE if profile else 0, reserved=0)
+        h = C.c_void_p()
+        rc = self._lib.gpx_create(C.byref(h), C.byref(cfg))
+        if rc != 0:
+            raise _abi.GpxError(rc, self._lib.gpx_last_error(None).decode())
+        self._h = h
+        self._fitted = False
+        self._alpha = None
+        self.info_ = 0
+        self.jitter_used_ = self.jitter
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise _abi.GpxError(rc, self._lib.gpx_last_error(self._h).decode())
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.gpx_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _as_input(self, a, name):
+        """-> (pointer, mem_kind, keepalive, torch_device_or_None, shape)"""
+        if _is_torch(a):
+            import torch
+            t = a.detach()
+            if t.dtype != torch.float64:
+                t = t.to(torch.float64)
+            t = t.contiguous()
+            if t.is_cuda:
+                if t.device.index != self.device:
+                    raise ValueError(f"{name} lives on cuda:{t.device.index}, handle on {self.device}")
+                torch.cuda.current_stream(t.device).synchronize()
+                return C.c_void_p(t.data_ptr()), _abi.MEM_DEVICE, t, t.device, tuple(t.shape)
+            a = t.numpy()
+        arr = np.ascontiguousarray(a, dtype=np.float64)
+        return C.c_void_p(arr.ctypes.data), _abi.MEM_HOST, arr, None, arr.shape
+
+    # -- API ----------------------------------------------------------------------------
+    def fit(self, X, y):
+        px, kx, keepx, devx, sx = self._as_input(X, "X")
+        py, ky, keepy, devy, sy = self._as_input(y, "y")
+        if len(sx) != 2:
+            raise ValueError("X must be (N, d)")
+        N, d = sx
+        if len(sy) not in (1, 2) or sy[0] != N:
+            raise ValueError("y must be (N,) or (N, k) with the same N as X")
+        if kx != ky:
+            raise ValueError("X and y must both be host arrays or both be device tensors")
+        k = 1 if len(sy) == 1 else sy[1]
+        if self.lengthscale.size not in (1, d):
+            raise ValueError("lengthscale must be scalar or have d entries")
+        self._y1d = len(sy) == 1
+        self._N, self._d, self._k = N, d, k
+        self._alpha = None
+        self._fitted = False
+        ls = self.lengthscale
+        jitter = self.jitter
+        info = C.c_int64(0)
+        for _ in range(max(1, self.max_tries)):
+            rc = self._lib.gpx_fit(self._h, px, py, N, d, k, _abi.dptr(ls), ls.size, self.variance,
+                                   self.noise, jitter, kx, C.byref(info))
+            self._check(rc)
+            self.info_ = int(info.value)
+            if self.info_ == 0:
+                break
+            jitter = max(jitter, 1e-12 * self.variance) * 10.0
+        else:
+            raise np.linalg.LinAlgError(
+                f"kernel matrix not positive definite (first bad pivot {self.info_}) after "
+                f"{self.max_tries} jitter escalations")
+        self.jitter_used_ = jitter
+        self._fitted = True
+        ld = C.c_double(0.0)
+        self._check(self._lib.gpx_logdet(self._h, C.byref(ld)))
+        self.log_det_ = float(ld.value)
+        return self
+
+    def predict(self, Xs, return_var=True, include_noise=False):
+        if not self._fitted:
+            raise RuntimeError("predict() before a successful fit()")
+        pq, kq, keepq, devq, sq = self._as_input(Xs, "Xs")
+        if len(sq) != 2 or sq[1] != self._d:
+            raise ValueError(f"Xs must be (M, {self._d})")
+        M = sq[0]
+        mshape = (M,) if self._y1d else (M, self._k)
+        if devq is not None:
+            import torch
+            mean = torch.empty(mshape, dtype=torch.float64, device=devq)
+            var = torch.empty((M,), dtype=torch.float64, device=devq) if return_var else None
+            pm = C.c_void_p(mean.data_ptr())
+            pv = C.c_void_p(var.data_ptr()) if return_var else None
+        else:
+            mean = np.empty(mshape, dtype=np.float64)
+            var = np.empty((M,), dtype=np.float64) if return_var else None
+            pm = C.c_void_p(mean.ctypes.data)
+            pv = C.c_void_p(var.ctypes.data) if return_var else None
+        self._check(self._lib.gpx_predict(self._h, pq, M, pm, pv, kq))
+        if not return_var:
+            return mean
+        if include_noise:
+            var += self.noise
+        return mean, var
+
+    @property
+    def alpha_(self):
+        if not self._fitted:
+            raise RuntimeError("no fit")
+        if self._alpha is None:
+            out = np.empty((self._N, self._k), dtype=np.float64)
+            self._check(self._lib.gpx_get_alpha(self._h, C.c_void_p(out.ctypes.data)))
+            self._alpha = out[:, 0].copy() if self._y1d else out
+        return self._alpha
+
+    @property
+    def timings_(self):
+        t = _abi.GpxTimings()
+        self._check(self._lib.gpx_get_timings(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def log_marginal_likelihood(self, y):
+        """-1/2 y^T alpha - 1/2 logdet - N/2 log(2 pi), summed over target columns."""
+        if _is_torch(y):
+            y = y.detach().cpu().numpy()
+        Y = np.asarray(y, dtype=np.float64).reshape(self._N, -1)
+        A = self.alpha_.reshape(self._N, -1)
+        n, k = Y.shape
+        return float(-0.5 * np.sum(Y * A) - 0.5 * k * self.log_det_
+                     - 0.5 * n * k * np.log(2.0 * np.pi))

@@ -1,0 +1,133 @@
+/* gpx.h — C ABI of libgpx.so: exact Gaussian-process regression on MI355X (gfx950).
+ *
+ * Drop-in boundary for the GP fit/predict hot path.  The upstream
+ * reference (/root/reference/GPmap.py) has NO fit/predict, no kernel matrix and no
+ * Cholesky (its only linalg call is np.linalg.norm, GPmap.py:120), so there is no
+ * reference FFI to mirror: each entry point below cites the SURVEY.md §8 row that
+ * defines it and, where one exists, the nearest reference code.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ types, no exceptions, no abort().
+ *   - return 0 = ok, <0 = API misuse / HIP / RCCL error (text via gpx_last_error).
+ *   - numerical failure is NOT an error code: *info > 0 is the 1-based index of the
+ *     first non-positive pivot (LAPACK potrf convention) and the call returns 0.
+ *   - all matrices are row-major, C-contiguous unless a leading dimension is given.
+ *   - the caller owns every pointer it passes; the library owns every device
+ *     allocation inside a handle and frees it in gpx_destroy.
+ *   - a handle is not thread-safe; distinct handles may be used from distinct threads.
+ *   - calls are synchronous at return.
+ */
+#ifndef GPX_H_
+#define GPX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPX_ABI_VERSION 1
+
+/* kernel family — SURVEY.md §8 row a1 (nearest reference code: the pairwise
+ * distance loop trajectories.calc_distance, GPmap.py:114-121, and the unused
+ * scipy.spatial.distance import, GPmap.py:10). */
+#define GPX_KERNEL_RBF 0      /* sf2 * exp(-r^2/2)                            */
+#define GPX_KERNEL_MATERN52 1 /* sf2 * (1 + sqrt5 r + 5 r^2/3) exp(-sqrt5 r)  */
+
+#define GPX_F64 0
+#define GPX_F32 1
+
+#define GPX_MEM_HOST 0   /* pointers are host memory; library copies H2D/D2H   */
+#define GPX_MEM_DEVICE 1 /* pointers are device memory on the handle's device  */
+
+#define GPX_FLAG_PROFILE 1 /* per-launch hipEvent timing of the Cholesky sub-phases */
+
+/* error codes */
+#define GPX_OK 0
+#define GPX_E_ARG (-1)     /* bad argument / state                               */
+#define GPX_E_HIP (-2)     /* HIP runtime error                                  */
+#define GPX_E_COMM (-3)    /* RCCL / communicator error                          */
+#define GPX_E_UNSUPPORTED (-4)
+#define GPX_E_NOMEM (-5)
+
+typedef struct gpx_handle gpx_handle;
+
+typedef struct gpx_config {
+  int32_t kernel;  /* GPX_KERNEL_*                                   */
+  int32_t dtype;   /* GPX_F64 | GPX_F32                              */
+  int32_t device;  /* HIP device ordinal this handle computes on     */
+  int32_t block;   /* Cholesky panel width nb (multiple of 128), 0 = default (512) */
+  int32_t rank;    /* this process' rank in the row-block shard (0 if world==1)    */
+  int32_t world;   /* number of GPUs sharing the Gram matrix (1 = unsharded)       */
+  int32_t flags;   /* GPX_FLAG_*                                     */
+  int32_t reserved;
+} gpx_config;
+
+/* per-phase wall times (ms, hipEvent on the handle's stream) of the LAST
+ * gpx_fit / gpx_predict — SURVEY.md §8(d). */
+typedef struct gpx_timings {
+  double h2d, kbuild, chol, solve, logdet, fit_total;          /* gpx_fit     */
+  double kstar, mean, trsm, var, d2h, predict_total;           /* gpx_predict */
+  double comm;                                                 /* RCCL time inside chol (sharded) */
+  /* Cholesky sub-phases, filled only with GPX_FLAG_PROFILE: */
+  double chol_diag, chol_trsm, chol_syrk;  /* summed ms                          */
+  double syrk_flops;                       /* algorithmic flops of all SYRK launches: n(n+1) nb each */
+  int64_t syrk_launches;
+  double kbuild_bytes;                     /* algorithmic bytes of the kernel build */
+} gpx_timings;
+
+/* ---- lifecycle ------------------------------------------------------------- */
+int gpx_abi_version(void);
+int gpx_device_count(int* count);
+int gpx_create(gpx_handle** out, const gpx_config* cfg);
+void gpx_destroy(gpx_handle* h);
+const char* gpx_last_error(gpx_handle* h); /* h may be NULL: last error of gpx_create */
+
+/* ---- hot path (SURVEY.md §8 rows a1,a3,a4 = fit; a2,a5,a6 = predict) --------- */
+/* K = sf2 k(X,X) + (sn2+jitter) I;  L = chol(K);  alpha = L^-T L^-1 y.
+ * X (N,d), y (N,k) row-major, dtype of the handle.  lengthscale: n_ls = 1 or d. */
+int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
+            const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter,
+            int32_t mem_kind, int64_t* info);
+
+/* mean (M,k) = K* alpha;  var (M) = sf2 - colsumsq(L^-1 K*^T)  (latent variance,
+ * raw — not clamped).  var may be NULL (mean only). */
+int gpx_predict(gpx_handle* h, const void* Xs, int64_t M, void* mean, void* var,
+                int32_t mem_kind);
+
+int gpx_get_alpha(gpx_handle* h, void* out /* (N,k) host */);
+int gpx_logdet(gpx_handle* h, double* out);
+int gpx_get_timings(gpx_handle* h, gpx_timings* out);
+
+/* ---- row-block sharding over RCCL ------------------------------ */
+/* One process per GPU.  Rank 0 calls gpx_comm_unique_id and ships the 128 bytes to
+ * the other ranks by any means (the Python host uses torch.distributed); every rank
+ * then calls gpx_comm_init on its handle (created with the same world, own rank). */
+int gpx_comm_unique_id(void* id128);
+int gpx_comm_init(gpx_handle* h, const void* id128);
+
+/* ---- kernel unit-test entry points (host buffers, fp64) ------------------------- */
+/* K (na,nb) = sf2 k(A,B) (+ diag_add on the diagonal when B == NULL, i.e. B = A). */
+int gpx_kernel_matrix(int32_t kernel, const double* A, int64_t na, const double* B, int64_t nb,
+                      int32_t d, const double* lengthscale, int32_t n_ls, double sf2,
+                      double diag_add, double* K /* (na, nb or na) */);
+/* in-place lower Cholesky of A (n,n), lda = n; n multiple of 64. Upper triangle
+ * is left untouched.  block = panel width (0 = default). */
+int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info);
+/* X (m,nb) <- X L^-T, L (nb,nb) lower; m, nb multiples of 64. */
+int gpx_trsm(double* X, int64_t m, const double* L, int64_t nb);
+/* C (m,n) -= A (m,k) B(n,k)^T.  lower != 0: only tiles on/below the diagonal
+ * (m == n required).  m,n multiples of 128, k multiple of 16. */
+int gpx_gemm_nt(double* C, int64_t m, int64_t n, const double* A, const double* B, int64_t k,
+                int32_t lower);
+/* fp64 MFMA layout probe: D (16,16) = A (16,4) B (4,16) through one
+ * v_mfma_f64_16x16x4_f64. */
+int gpx_mfma_probe(const double* A, const double* B, double* D);
+/* microbenchmarks quoted beside the rooflines: sustained fp64 MFMA
+ * TFLOP/s of a register-resident loop and HBM GB/s of a streaming copy. */
+int gpx_microbench(double* mfma_tflops, double* copy_gbs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H_ */

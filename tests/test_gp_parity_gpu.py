@@ -1,0 +1,151 @@
+"""GPU: end-to-end fit()/predict() parity of the HIP path against the oracle and the
+golden fixtures.  Bar: 1e-6 relative fp64 (north_star), elementwise
+  |d mean| <= 1e-6 * max(|mean_ref|, 1e-6),  |d var| <= 1e-6 * max(var_ref, 1e-6 * sf2).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from gaussianprocesspathmodelling_amd import GP
+from oracle.gp_oracle import OracleGP, kernel_matrix, synthetic_problem
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def assert_parity(mean, var, mean_ref, var_ref, sf2):
+    dm = np.abs(mean - mean_ref) / np.maximum(np.abs(mean_ref), 1e-6)
+    dv = np.abs(var - var_ref) / np.maximum(var_ref, 1e-6 * sf2)
+    assert dm.max() <= RTOL, f"mean rel err {dm.max():.3e}"
+    assert dv.max() <= RTOL, f"var rel err {dv.max():.3e}"
+    return dm.max(), dv.max()
+
+
+@pytest.mark.parametrize("name", ["G1", "G2", "G3"])
+def test_golden_fixtures(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    sf2 = float(z["variance"])
+    gp = GP(kernel=str(z["kernel"]), lengthscale=z["lengthscale"], variance=sf2,
+            noise=float(z["noise"]), jitter=float(z["jitter"]))
+    gp.fit(z["X"], z["y"])
+    assert gp.info_ == 0
+    mean, var = gp.predict(z["Xs"])
+    assert_parity(mean, var, z["mean"], z["var"], sf2)
+    assert_parity(mean, var, z["sk_mean"], z["sk_var"], sf2)   # scikit-learn's numbers too
+    assert np.max(np.abs(gp.alpha_ - z["alpha"])) <= 1e-7 * np.max(np.abs(z["alpha"]))
+    assert abs(gp.log_det_ - float(z["logdet"])) <= 1e-10 * abs(float(z["logdet"]))
+    assert abs(gp.log_marginal_likelihood(z["y"]) - float(z["lml"])) <= 1e-9 * abs(float(z["lml"]))
+    m_only = gp.predict(z["Xs"], return_var=False)
+    assert np.array_equal(m_only, mean)
+    gp.close()
+
+
+@pytest.mark.parametrize("N,d,M,kernel,ls,block", [
+    (1000, 3, 77, "rbf", 0.25, 0),                 # ragged: N, M not multiples of any tile
+    (1, 2, 1, "rbf", 0.25, 0),                     # smallest problem
+    (129, 1, 300, "matern52", 0.4, 128),
+    (1500, 3, 130, "matern52", (0.3, 0.2, 0.25), 256),
+    (2500, 2, 64, "rbf", (0.3, 0.2), 512),
+])
+def test_ragged_sizes_vs_oracle(N, d, M, kernel, ls, block):
+    X, y, Xs = synthetic_problem(N, d, M, seed=N + M)
+    ref = OracleGP(kernel, ls, 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    with GP(kernel, ls, 1.5, 1e-2, jitter=0.0, block=block) as gp:
+        mean, var = gp.fit(X, y).predict(Xs)
+        assert_parity(mean, var, mr, vr, 1.5)
+        assert abs(gp.log_det_ - ref.log_det_) <= 1e-9 * max(1.0, abs(ref.log_det_))
+
+
+def test_config_C2_n8192_full_oracle():
+    """BASELINE.json configs[1]: N=8192, d=3, RBF, fp64, M=4096 — full CPU oracle."""
+    X, y, Xs = synthetic_problem(8192, 3, 4096)
+    ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0) as gp:
+        mean, var = gp.fit(X, y).predict(Xs)
+        em, ev = assert_parity(mean, var, mr, vr, 1.5)
+        print(f"C2 parity: mean {em:.2e} var {ev:.2e}; timings {gp.timings_}")
+        assert abs(gp.log_det_ - ref.log_det_) <= 1e-9 * abs(ref.log_det_)
+
+
+def test_multi_output_and_noise_flag():
+    X, y, Xs = synthetic_problem(700, 3, 50, seed=11)
+    Y = np.stack([y, np.cos(y), 2 * y - 1], axis=1)
+    ref = OracleGP("rbf", 0.3, 1.2, 2e-2, jitter=0.0).fit(X, Y)
+    mr, vr = ref.predict(Xs, include_noise=True)
+    with GP("rbf", 0.3, 1.2, 2e-2, jitter=0.0) as gp:
+        mean, var = gp.fit(X, Y).predict(Xs, include_noise=True)
+        assert mean.shape == (50, 3)
+        for c in range(3):
+            assert_parity(mean[:, c], var, mr[:, c], vr, 1.2)
+        assert gp.alpha_.shape == (700, 3)
+
+
+def test_refit_reuses_handle_and_permutation_invariance():
+    X, y, Xs = synthetic_problem(640, 2, 40, seed=2)
+    with GP("matern52", 0.35, 1.0, 1e-2) as gp:
+        m1, v1 = gp.fit(X, y).predict(Xs)
+        p = np.random.default_rng(0).permutation(640)
+        m2, v2 = gp.fit(X[p], y[p]).predict(Xs)
+        assert np.max(np.abs(m1 - m2)) <= 1e-9 and np.max(np.abs(v1 - v2)) <= 1e-9
+        assert np.all(v1 > -1e-9) and np.all(v1 <= 1.0 + 1e-12)
+
+
+def test_not_positive_definite_escalates_then_raises():
+    X = np.zeros((200, 2))
+    X[:, 0] = np.repeat(np.linspace(0, 1, 100), 2)       # duplicated points, zero noise
+    y = np.sin(X[:, 0])
+    with GP("rbf", 0.5, 1.0, noise=0.0, jitter=0.0, max_tries=1) as gp:
+        with pytest.raises(np.linalg.LinAlgError):
+            gp.fit(X, y)
+        assert gp.info_ > 0
+        with pytest.raises(RuntimeError):
+            gp.predict(X[:3])
+    with GP("rbf", 0.5, 1.0, noise=0.0, jitter=0.0, max_tries=12) as gp:
+        gp.fit(X, y)                                       # jitter x10 per try until PD
+        assert gp.info_ == 0 and gp.jitter_used_ > 0.0
+
+
+def test_device_tensor_inputs():
+    torch = pytest.importorskip("torch")
+    X, y, Xs = synthetic_problem(900, 3, 120, seed=4)
+    ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    dev = torch.device("cuda:0")
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0, device=0) as gp:
+        gp.fit(torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev))
+        mean, var = gp.predict(torch.from_numpy(Xs).to(dev))
+        assert mean.is_cuda and var.is_cuda
+        assert_parity(mean.cpu().numpy(), var.cpu().numpy(), mr, vr, 1.5)
+
+
+def test_config_C3_n65536_properties():
+    """BASELINE.json configs[2] (the bench workload): N=65536, d=3, RBF, M=4096.  No full CPU
+    oracle at this size in the test-suite (34 GB, minutes); size-independent properties:
+      (i)  residual  || K alpha - y || on 512 random rows, K rows regenerated by the oracle kernel;
+      (ii) predicting AT training points: mean_i = y_i - (sn2 + jitter) alpha_i  (exact identity);
+      (iii) 0 <= var <= sf2 and var at training points <= sn2-ish (posterior shrinkage).
+    """
+    N, d, M = 65536, 3, 4096
+    X, y, Xs = synthetic_problem(N, d, M)
+    sf2, sn2 = 1.5, 1e-2
+    with GP("rbf", 0.25, sf2, sn2, jitter=0.0, profile=True) as gp:
+        gp.fit(X, y)
+        assert gp.info_ == 0
+        alpha = gp.alpha_
+        rows = np.random.default_rng(1).choice(N, 512, replace=False)
+        Kr = kernel_matrix(X[rows], X, "rbf", 0.25, sf2)
+        Kr[np.arange(512), rows] += sn2
+        resid = np.abs(Kr @ alpha - y[rows])
+        assert resid.max() <= 1e-8 * np.abs(y).max(), resid.max()
+        mean_t, var_t = gp.predict(X[rows])
+        assert np.max(np.abs(mean_t - (y[rows] - sn2 * alpha[rows]))) <= 1e-8
+        assert np.all(var_t > 0) and np.all(var_t < sn2)
+        mean, var = gp.predict(Xs)
+        assert np.all(np.isfinite(mean)) and np.all(var > 0) and np.all(var < sf2)
+        # mean through an independent route: K* alpha on the CPU for 256 test points
+        Ks = kernel_matrix(Xs[:256], X, "rbf", 0.25, sf2)
+        assert np.max(np.abs(Ks @ alpha - mean[:256])) <= 1e-9 * max(1.0, np.abs(mean).max())
+        print("C3 timings:", gp.timings_)

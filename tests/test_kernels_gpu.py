@@ -1,0 +1,125 @@
+"""GPU: each HIP kernel family against the numpy oracle pieces, through the C ABI's
+unit-test entry points (include/gpx.h).  Tolerances: fp64, stated per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gaussianprocesspathmodelling_amd import _abi
+from oracle.gp_oracle import chol_lower, kernel_matrix, trsm_right_lower_trans
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+def test_mfma_f64_layout(gpx):
+    """A/B/D lane maps of v_mfma_f64_16x16x4_f64, checked with asymmetric integer data."""
+    rng = np.random.default_rng(0)
+    A = rng.integers(-8, 9, (16, 4)).astype(np.float64)
+    B = rng.integers(-8, 9, (4, 16)).astype(np.float64)
+    D = np.zeros((16, 16))
+    assert gpx.gpx_mfma_probe(_abi.dptr(A), _abi.dptr(B), _abi.dptr(D)) == 0
+    assert np.array_equal(D, A @ B)
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern52"])
+@pytest.mark.parametrize("n,d,ls", [(64, 3, 0.25), (200, 2, 0.25), (333, 3, (0.3, 0.2, 0.25)),
+                                    (130, 1, 0.5), (96, 5, 0.7)])
+def test_kernel_matrix_symmetric(gpx, kernel, n, d, ls):
+    rng = np.random.default_rng(n + d)
+    A = rng.uniform(size=(n, d))
+    lsv = np.atleast_1d(np.asarray(ls, float))
+    K = np.full((n, n), np.nan)
+    rc = gpx.gpx_kernel_matrix(_abi.KERNEL_IDS[kernel], _abi.dptr(A), n, None, 0, d, _abi.dptr(lsv),
+                               lsv.size, 1.5, 0.0123, _abi.dptr(K))
+    assert rc == 0
+    ref = kernel_matrix(A, A, kernel, ls, 1.5)
+    ref[np.diag_indices(n)] += 0.0123
+    # tiles strictly above the diagonal are not built; inside diagonal tiles both halves are
+    low = np.tril_indices(n)
+    err = np.abs(K[low] - ref[low]) / np.abs(ref[low])
+    assert err.max() <= 1e-12, err.max()
+
+
+@pytest.mark.parametrize("kernel", ["rbf", "matern52"])
+def test_kernel_matrix_cross(gpx, kernel):
+    rng = np.random.default_rng(7)
+    A = rng.uniform(size=(77, 3))
+    B = rng.uniform(size=(300, 3))
+    ls = np.array([0.3, 0.2, 0.25])
+    K = np.full((77, 300), np.nan)
+    rc = gpx.gpx_kernel_matrix(_abi.KERNEL_IDS[kernel], _abi.dptr(A), 77, _abi.dptr(B), 300, 3,
+                               _abi.dptr(ls), 3, 1.5, 0.0, _abi.dptr(K))
+    assert rc == 0
+    ref = kernel_matrix(A, B, kernel, ls, 1.5)
+    assert np.max(np.abs(K - ref) / np.abs(ref)) <= 1e-12
+
+
+@pytest.mark.parametrize("m,n,k,lower", [(128, 128, 16, 0), (128, 256, 64, 0), (256, 384, 512, 0),
+                                         (64, 192, 32, 0), (192, 64, 528, 0), (384, 384, 512, 1),
+                                         (320, 320, 64, 1)])
+def test_gemm_nt(gpx, m, n, k, lower):
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    A = rng.standard_normal((m, k))
+    B = A if lower else rng.standard_normal((n, k))
+    C0 = rng.standard_normal((m, n))
+    Cg = C0.copy()
+    assert gpx.gpx_gemm_nt(_abi.dptr(Cg), m, n, _abi.dptr(A), _abi.dptr(B), k, lower) == 0
+    ref = C0 - A @ B.T
+    tile = 128 if (m % 128 == 0 and n % 128 == 0) else 64
+    scale = np.abs(A) @ np.abs(B.T) + np.abs(C0)
+    err = np.abs(Cg - ref) / scale
+    if lower:
+        ti = np.arange(m)[:, None] // tile
+        tj = np.arange(n)[None, :] // tile
+        done = tj <= ti
+        assert err[done].max() <= 4 * k * EPS
+        assert np.array_equal(Cg[~done], C0[~done]), "tiles above the diagonal must be untouched"
+    else:
+        assert err.max() <= 4 * k * EPS
+
+
+@pytest.mark.parametrize("m,nb", [(64, 64), (128, 64), (192, 512), (64, 320)])
+def test_trsm_right_lower_trans(gpx, m, nb):
+    rng = np.random.default_rng(m + nb)
+    G = rng.standard_normal((nb, nb))
+    L = chol_lower(G @ G.T + nb * np.eye(nb))
+    X0 = rng.standard_normal((m, nb))
+    X = X0.copy()
+    Lc = np.ascontiguousarray(np.tril(L))
+    assert gpx.gpx_trsm(_abi.dptr(X), m, _abi.dptr(Lc), nb) == 0
+    ref = trsm_right_lower_trans(X0, L)
+    # backward error of the solve
+    resid = np.abs(X @ L.T - X0).max() / (np.abs(X).max() * np.abs(L).max() * nb)
+    assert resid <= 50 * EPS, resid
+    assert np.max(np.abs(X - ref)) <= 1e-10 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("n,block", [(64, 0), (128, 128), (512, 0), (1024, 0), (1152, 256), (2048, 512)])
+def test_potrf_backward_error(gpx, n, block):
+    rng = np.random.default_rng(n)
+    Xp = rng.uniform(size=(n, 3))
+    K = kernel_matrix(Xp, Xp, "rbf", 0.25, 1.5)
+    K[np.diag_indices(n)] += 1e-2
+    A = np.tril(K) + np.triu(np.full((n, n), 777.0), 1)   # poison the upper triangle
+    info = C.c_int64(-1)
+    assert gpx.gpx_potrf(_abi.dptr(A), n, block, C.byref(info)) == 0
+    assert info.value == 0
+    assert np.all(np.triu(A, 1) == 777.0), "upper triangle must be left untouched"
+    L = np.tril(A)
+    berr = np.linalg.norm(L @ L.T - K) / np.linalg.norm(K)
+    assert berr <= 8 * n * EPS, berr
+    ref = chol_lower(K)
+    assert np.max(np.abs(L - ref)) <= 1e-9 * np.max(np.abs(ref))
+
+
+def test_potrf_reports_first_bad_pivot(gpx):
+    n = 256
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal((n, n))
+    K = G @ G.T + n * np.eye(n)
+    K[150, 150] = -1.0      # leading 150x150 minor stays PD, pivot 151 fails
+    A = np.tril(K)
+    info = C.c_int64(0)
+    assert gpx.gpx_potrf(_abi.dptr(A), n, 128, C.byref(info)) == 0
+    assert info.value == 151
