@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — GP fit+predict throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: ``fit(X, y)``
+(kernel build, blocked Cholesky, alpha solves) followed by ``predict(Xs)`` (cross
+kernel, mean, variance TRSM) on BASELINE.json configs[2] — N=65536, d=3, RBF, fp64,
+M=4096 (M fixed by SURVEY.md §8) — with X, y, Xs already resident in HBM (torch CUDA
+tensors are only the containers; all arithmetic is libgpx.so).
+
+N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU, every
+rank runs its own replica of the workload (independent GPs — e.g. one per path
+cluster — need no data-path collective), value = points of all ranks / max-over-ranks
+time, ``"scaling": "weak"``.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline     — the dominant kernel (trailing SYRK of the blocked Cholesky, fp64 MFMA):
+                 algorithmic flops n(n+1)nb per launch / hipEvent time per launch, both
+                 summed over the launches of the timed steps (library events on the
+                 library's stream, GPX_FLAG_PROFILE)
+  cpu_baseline — the NumPy/SciPy oracle (oracle/gp_oracle.py) timed on this host's cores
+                 on a bounded sample (N=8192, same generator), rank 0, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[2]; hyper-parameters of SURVEY.md §8(d)
+N_TRAIN, DIM, M_TEST = 65536, 3, 4096
+KERNEL, LENGTHSCALE, SF2, SN2 = "rbf", 0.25, 1.5, 1e-2
+PEAK_FP64_MFMA_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 FLOP/clk (v_mfma_f64_16x16x4: 2048 FLOP / 64 clk) x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic(N, d, M, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0.0, 1.0, (N, d))
+    Xs = rng.uniform(0.0, 1.0, (M, d))
+    y = (np.sin(2.0 * np.pi * X[:, 0]) + 0.5 * np.cos(3.0 * X[:, 1:].sum(axis=1))
+         + 0.1 * rng.standard_normal(N))
+    return X, y, Xs
+
+
+def cpu_baseline(n_sample=8192):
+    """Oracle fit+predict on the host cores, bounded sample (about 10-30 s)."""
+    import numpy as np
+    from oracle.gp_oracle import OracleGP
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [f"{p.get('internal_api')}:{p.get('num_threads')}" for p in threadpool_info()]
+    except Exception:
+        blas = []
+    X, y, Xs = synthetic(n_sample, DIM, M_TEST, 12345)
+    t0 = time.perf_counter()
+    gp = OracleGP(KERNEL, LENGTHSCALE, SF2, SN2, jitter=0.0).fit(X, y)
+    t1 = time.perf_counter()
+    gp.predict(Xs)
+    t2 = time.perf_counter()
+    tm = gp.timings_
+    r = N_TRAIN / n_sample
+    # extrapolate each phase to N=65536 by its algorithmic work
+    est = (tm["kbuild"] * r ** 2 + tm["chol"] * r ** 3 + tm["solve"] * r ** 2
+           + (tm["kstar"] + tm["mean"]) * r + (tm["trsm"] + tm["var"]) * r ** 2) * 1e-3
+    cores = os.cpu_count() or 1
+    return {
+        "value": (n_sample + M_TEST) / (t2 - t0), "unit": "points/s", "cores": cores,
+        "kind": "port",
+        "sample": (f"oracle/gp_oracle.py (NumPy/SciPy, BLAS threads {blas}) full fit+predict at "
+                   f"N={n_sample} d={DIM} M={M_TEST} RBF fp64, same generator: fit {t1 - t0:.2f} s "
+                   f"(kbuild {tm['kbuild']:.0f} ms, chol {tm['chol']:.0f} ms, solve {tm['solve']:.0f} ms), "
+                   f"predict {t2 - t1:.2f} s; phase-wise extrapolation to N={N_TRAIN}: "
+                   f"{est:.0f} s/step = {(N_TRAIN + M_TEST) / est:.1f} points/s"),
+        "extrapolated_points_per_s_at_workload": (N_TRAIN + M_TEST) / est,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=N_TRAIN, help="override N (debug only; invalidates the metric)")
+    ap.add_argument("--m", type=int, default=M_TEST)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-microbench", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from gaussianprocesspathmodelling_amd import GP, _abi
+
+    N, M = args.n, args.m
+    X, y, Xs = synthetic(N, DIM, M, 12345 + rank)      # every replica its own draw
+    Xd, yd, Xsd = (torch.from_numpy(a).to(dev) for a in (X, y, Xs))
+    gp = GP(KERNEL, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local])
+            torch.cuda.synchronize(dev)
+
+    def step():
+        gp.fit(Xd, yd)
+        mean, var = gp.predict(Xsd)
+        return mean, var, gp.timings_
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    acc = {}
+    for _ in range(args.steps):
+        mean, var, tm = step()
+        for k_, v_ in tm.items():
+            acc[k_] = acc.get(k_, 0.0) + v_
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ok = bool(torch.isfinite(mean).all().item() and (var > 0).all().item())
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        syrk_ms = acc["chol_syrk"]
+        syrk_tflops = acc["syrk_flops"] / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+        launches = int(acc["syrk_launches"])
+        phases = {k_: round(acc[k_] / steps, 3) for k_ in
+                  ("h2d", "kbuild", "chol", "chol_diag", "chol_trsm", "chol_syrk", "solve", "logdet",
+                   "fit_total", "kstar", "mean", "trsm", "var", "d2h", "predict_total")}
+        kb_ms = acc["kbuild"] / steps
+        out = {
+            "metric": "gp_fit_predict_points_per_sec", "value": world * (N + M) * steps / elapsed,
+            "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C3: exact GP fit+predict, N={N} d={DIM} RBF fp64, M={M}, "
+                                   f"inputs resident in HBM", "N": N, "d": DIM, "M": M,
+                       "kernel": KERNEL, "block": args.block or 512,
+                       "parallelism": "1 gpu" if world == 1 else f"{world} independent replicas"},
+            "outputs_finite": ok,
+            "phases_ms": phases,
+            "roofline": {
+                "kernel": "gemm_nt_kernel<128,LOWER> (trailing SYRK of the blocked Cholesky)",
+                "bound": "mfma", "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                "launches": launches,
+                "flops_per_launch": acc["syrk_flops"] / max(1, launches),
+                "avg_launch_ms": syrk_ms / max(1, launches)},
+            "kbuild": {"bound": "hbm", "achieved": acc["kbuild_bytes"] / steps / (kb_ms * 1e-3) / 1e9
+                       if kb_ms > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s"},
+        }
+        out["kbuild"]["frac"] = out["kbuild"]["achieved"] / PEAK_HBM_GBS
+        chol_ms = acc["chol"] / steps
+        out["cholesky_tflops"] = (N ** 3 / 3.0) / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
+        if world == 1 and not args.no_microbench:
+            import ctypes as C
+            a, b = C.c_double(0), C.c_double(0)
+            if _abi.load().gpx_microbench(C.byref(a), C.byref(b)) == 0:
+                out["microbench"] = {"mfma_f64_loop_tflops": a.value, "stream_copy_gbs": b.value}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    gp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

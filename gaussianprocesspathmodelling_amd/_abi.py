@@ -72,11 +72,36 @@ class GpxError(RuntimeError):
         self.code = code
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so / libhsa-runtime64.so (SONAME libamdhip64.so.7, loaded by file
+    name); a second copy from /opt/rocm in the same process cannot see the GPU
+    ("No HIP GPUs are available").  When torch is installed, map ITS runtime first:
+    libgpx's DT_NEEDED libamdhip64.so.7 then binds to that object by SONAME, and a
+    later (or earlier) `import torch` finds the same file already mapped.  torch itself
+    is not imported here."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
 def load():
     """dlopen csrc/libgpx.so and attach signatures.  Raises if it is not there."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m gaussianprocesspathmodelling_amd.build` "

@@ -111,8 +111,9 @@ int gpx_comm_init(gpx_handle* h, const void* id128);
 int gpx_kernel_matrix(int32_t kernel, const double* A, int64_t na, const double* B, int64_t nb,
                       int32_t d, const double* lengthscale, int32_t n_ls, double sf2,
                       double diag_add, double* K /* (na, nb or na) */);
-/* in-place lower Cholesky of A (n,n), lda = n; n multiple of 64. Upper triangle
- * is left untouched.  block = panel width (0 = default). */
+/* in-place lower Cholesky of A (n,n), lda = n; n multiple of 64.  The strictly upper
+ * triangle is never read and is scratch on return (diagonal tiles are updated whole).
+ * block = panel width (0 = default). */
 int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info);
 /* X (m,nb) <- X L^-T, L (nb,nb) lower; m, nb multiples of 64. */
 int gpx_trsm(double* X, int64_t m, const double* L, int64_t nb);
