@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) void mfma_probe_kernel(const double* A, const d
 }
 
 // register-resident fp64 MFMA loop: 16 independent accumulators per wave
-__global__ __launch_bounds__(256) void mfma_loop_kernel(double* sink, int iters) {
+__global__ __launch_bounds__(256, 2) void mfma_loop_kernel(double* sink, int iters) {
   const int l = threadIdx.x;
   double a = 1.0 + 1e-9 * l, b = 1.0 - 1e-9 * l;
   v4d acc[16];
