@@ -153,7 +153,7 @@ def main():
         syrk_tflops = acc["syrk_flops"] / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
         launches = int(acc["syrk_launches"])
         phases = {k_: round(acc[k_] / steps, 3) for k_ in
-                  ("h2d", "kbuild", "chol", "chol_diag", "chol_trsm", "chol_syrk", "solve", "logdet",
+                  ("h2d", "kbuild", "chol", "chol_diag", "chol_trsm", "chol_strip", "chol_syrk", "solve", "logdet",
                    "fit_total", "kstar", "mean", "trsm", "var", "d2h", "predict_total")}
         kb_ms = acc["kbuild"] / steps
         out = {

@@ -28,7 +28,7 @@ class GpxTimings(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("h2d", "kbuild", "chol", "solve", "logdet", "fit_total",
                  "kstar", "mean", "trsm", "var", "d2h", "predict_total",
-                 "comm", "chol_diag", "chol_trsm", "chol_syrk", "syrk_flops")] + \
+                 "comm", "chol_diag", "chol_trsm", "chol_strip", "chol_syrk", "syrk_flops")] + \
                [("syrk_launches", C.c_int64), ("kbuild_bytes", C.c_double)]
 
     def as_dict(self):

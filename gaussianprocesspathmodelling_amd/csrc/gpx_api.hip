@@ -51,7 +51,8 @@ struct DevBuf {
 struct gpx_handle {
   gpx_config cfg{};
   int nb = 512;
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr;   // main stream
+  hipStream_t st2 = nullptr;  // look-ahead (panel) stream, high priority
   std::string err;
   gpx_timings tm{};
   // fitted state
@@ -117,16 +118,18 @@ struct PhaseScope {
   gpx_handle* h;
   Phase ph;
   bool on;
-  PhaseScope(gpx_handle* h_, double* target, bool enable = true) : h(h_), on(enable) {
+  hipStream_t s;
+  PhaseScope(gpx_handle* h_, double* target, bool enable = true, hipStream_t stream = nullptr)
+      : h(h_), on(enable), s(stream ? stream : h_->st) {
     if (!on) return;
     ph.a = next_event(h);
     ph.b = next_event(h);
     ph.target = target;
-    if (ph.a) (void)hipEventRecord(ph.a, h->st);
+    if (ph.a) (void)hipEventRecord(ph.a, s);
   }
   ~PhaseScope() {
     if (!on) return;
-    if (ph.b) (void)hipEventRecord(ph.b, h->st);
+    if (ph.b) (void)hipEventRecord(ph.b, s);
     if (ph.a && ph.b) h->phases.push_back(ph);
   }
 };
@@ -142,47 +145,88 @@ void collect_phases(gpx_handle* h) {
 }
 
 // ---- blocked right-looking Cholesky, in place on the lower triangle -------------------
-// A [n][ld]; Winv [n/64][64*64]; P [n][ldp] compact panel; n multiple of 64 (128 when
-// n > nb).  Two levels: panels of width nb; inside a panel's diagonal block, 64-wide
-// sub-panels whose diagonal is factorised by the one-workgroup POTF2.
-void chol_enqueue(gpx_handle* h, double* A, int64_t ld, int64_t n, int nb, double* Winv, double* P,
-                  int64_t ldp, int* info, int64_t gidx0, bool profile) {
-  hipStream_t st = h->st;
-  for (int64_t o = 0; o < n; o += nb) {
-    const int nbp = (int)std::min<int64_t>(nb, n - o);
+// A [n][ld]; Winv [n/64][64*64]; P = two compact panel buffers [n][ldp]; n multiple of
+// 64 (128 when n > nb).  Two levels: panels of width nb; inside a panel's diagonal block,
+// 64-wide sub-panels whose diagonal is factorised by the one-workgroup POTF2.
+//
+// One-panel look-ahead: the trailing update of step p is split into the STRIP (the nb
+// columns that form panel p+1) and the REST.  As soon as the strip is done, the
+// high-priority stream st2 factorises diagonal block p+1 and solves panel p+1 (into the
+// other P buffer) while the main stream runs the rest of update p; the two streams
+// touch disjoint columns of A.
+
+// diagonal block [o, o+nbp) on stream s
+void diag_enqueue(double* A, int64_t ld, int64_t o, int nbp, double* Winv, int* info,
+                  int64_t gidx0, hipStream_t s) {
+  for (int q = 0; q < nbp / KB; ++q) {
+    const int64_t oq = o + (int64_t)q * KB;
+    double* Aqq = A + oq * ld + oq;
+    double* Wq = Winv + (oq / KB) * (KB * KB);
+    launch_potf2_64(Aqq, ld, Wq, gidx0 + oq, info, s);
+    const int64_t rem = o + nbp - (oq + KB);
+    if (rem > 0) {
+      double* panel = A + (oq + KB) * ld + oq;
+      launch_trsm_rlt(panel, ld, rem, Aqq, ld, Wq, KB, nullptr, 0, s);
+      launch_gemm_nt(64, A + (oq + KB) * ld + (oq + KB), ld, panel, ld, panel, ld, rem, rem, KB, 1,
+                     0, s);
+    }
+  }
+}
+
+void chol_enqueue(gpx_handle* h, double* A, int64_t ld, int64_t n, int nb, double* Winv, double* P0,
+                  double* P1, int64_t ldp, int* info, int64_t gidx0, bool profile) {
+  hipStream_t s0 = h->st, s1 = h->st2;
+  double* Pbuf[2] = {P0, P1};
+  // prologue: panel 0 on the main stream
+  {
+    const int nb0 = (int)std::min<int64_t>(nb, n);
     {
       PhaseScope ps(h, &h->tm.chol_diag, profile);
-      for (int q = 0; q < nbp / KB; ++q) {
-        const int64_t oq = o + (int64_t)q * KB;
-        double* Aqq = A + oq * ld + oq;
-        double* Wq = Winv + (oq / KB) * (KB * KB);
-        launch_potf2_64(Aqq, ld, Wq, gidx0 + oq, info, st);
-        const int64_t rem = o + nbp - (oq + KB);
-        if (rem > 0) {
-          double* panel = A + (oq + KB) * ld + oq;
-          launch_trsm_rlt(panel, ld, rem, Aqq, ld, Wq, KB, nullptr, 0, st);
-          launch_gemm_nt(64, A + (oq + KB) * ld + (oq + KB), ld, panel, ld, panel, ld, rem, rem, KB,
-                         1, 0, st);
-        }
+      diag_enqueue(A, ld, 0, nb0, Winv, info, gidx0, s0);
+    }
+    if (n - nb0 > 0) {
+      PhaseScope ps(h, &h->tm.chol_trsm, profile);
+      launch_trsm_rlt(A + (int64_t)nb0 * ld, ld, n - nb0, A, ld, Winv, nb0, Pbuf[0], ldp, s0);
+    }
+  }
+  int step = 0;
+  for (int64_t o = 0; o < n; o += nb, ++step) {
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    const int64_t t0 = o + nbp;          // first trailing row/col
+    const int64_t ntrail = n - t0;
+    if (ntrail <= 0) break;
+    double* Pc = Pbuf[step & 1];         // panel of this step, rows [t0, n)
+    double* Pn = Pbuf[(step + 1) & 1];
+    const int nbn = (int)std::min<int64_t>(nb, ntrail);  // width of the next panel
+    const int64_t nrest = ntrail - nbn;
+    const int tile = (ntrail % 128 == 0 && nbn % 128 == 0) ? 128 : 64;
+    {  // STRIP: rows [t0, n) x cols [t0, t0+nbn), tiles on/below the diagonal
+      PhaseScope ps(h, &h->tm.chol_strip, profile);
+      launch_gemm_nt(tile, A + t0 * ld + t0, ld, Pc, ldp, Pc, ldp, ntrail, nbn, nbp, 2, 0, s0);
+    }
+    hipEvent_t e_strip = next_event(h), e_panel = next_event(h);
+    (void)hipEventRecord(e_strip, s0);
+    (void)hipStreamWaitEvent(s1, e_strip, 0);
+    {  // look-ahead stream: factor diagonal block p+1, solve panel p+1
+      {
+        PhaseScope ps(h, &h->tm.chol_diag, profile, s1);
+        diag_enqueue(A, ld, t0, nbn, Winv, info, gidx0, s1);
+      }
+      if (nrest > 0) {
+        PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
+        launch_trsm_rlt(A + (t0 + nbn) * ld + t0, ld, nrest, A + t0 * ld + t0, ld,
+                        Winv + (t0 / KB) * (KB * KB), nbn, Pn, ldp, s1);
       }
     }
-    const int64_t ntrail = n - (o + nbp);
-    if (ntrail > 0) {
-      double* panel = A + (o + nbp) * ld + o;
-      {
-        PhaseScope ps(h, &h->tm.chol_trsm, profile);
-        launch_trsm_rlt(panel, ld, ntrail, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, P,
-                        ldp, st);
-      }
-      {
-        PhaseScope ps(h, &h->tm.chol_syrk, profile);
-        const int tile = (ntrail % 128 == 0) ? 128 : 64;
-        launch_gemm_nt(tile, A + (o + nbp) * ld + (o + nbp), ld, P, ldp, P, ldp, ntrail, ntrail, nbp,
-                       1, 0, st);
-      }
-      h->tm.syrk_flops += (double)ntrail * (double)(ntrail + 1) * (double)nbp;
+    (void)hipEventRecord(e_panel, s1);
+    if (nrest > 0) {  // REST: lower triangle of the trailing matrix beyond the strip
+      PhaseScope ps(h, &h->tm.chol_syrk, profile);
+      launch_gemm_nt(tile, A + (t0 + nbn) * ld + (t0 + nbn), ld, Pc + (int64_t)nbn * ldp, ldp,
+                     Pc + (int64_t)nbn * ldp, ldp, nrest, nrest, nbp, 1, 0, s0);
+      h->tm.syrk_flops += (double)nrest * (double)(nrest + 1) * (double)nbp;
       h->tm.syrk_launches += 1;
     }
+    (void)hipStreamWaitEvent(s0, e_panel, 0);
   }
 }
 
@@ -270,8 +314,12 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
   if (!h) return fail(nullptr, GPX_E_NOMEM, "gpx_create: out of host memory");
   h->cfg = *cfg;
   h->nb = nb;
+  int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(cfg->device) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
+      hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithPriority(&h->st2, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+    if (h->st) (void)hipStreamDestroy(h->st);
     delete h;
     return fail(nullptr, GPX_E_HIP, "gpx_create: hipSetDevice/hipStreamCreate failed");
   }
@@ -283,11 +331,13 @@ void gpx_destroy(gpx_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device);
   if (h->st) (void)hipStreamSynchronize(h->st);
+  if (h->st2) (void)hipStreamSynchronize(h->st2);
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout})
     release(*b);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->st) (void)hipStreamDestroy(h->st);
+  if (h->st2) (void)hipStreamDestroy(h->st2);
   delete h;
 }
 
@@ -318,7 +368,7 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
   const bool profile = (h->cfg.flags & GPX_FLAG_PROFILE) != 0;
   gpx_timings& tm = h->tm;
   tm.h2d = tm.kbuild = tm.chol = tm.solve = tm.logdet = tm.fit_total = 0;
-  tm.chol_diag = tm.chol_trsm = tm.chol_syrk = tm.syrk_flops = tm.comm = 0;
+  tm.chol_diag = tm.chol_trsm = tm.chol_strip = tm.chol_syrk = tm.syrk_flops = tm.comm = 0;
   tm.syrk_launches = 0;
   tm.kbuild_bytes = 8.0 * ((double)N * (double)(N + 1) / 2.0 + (double)N * d);
 
@@ -329,7 +379,7 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
   if ((rc = ensure(h, h->ls, 32 * 8))) return rc;
   if ((rc = ensure(h, h->K, (size_t)Npad * ld * 8))) return rc;
   if ((rc = ensure(h, h->Winv, (size_t)(Npad / KB) * KB * KB * 8))) return rc;
-  if ((rc = ensure(h, h->P, (size_t)Npad * ldp * 8))) return rc;
+  if ((rc = ensure(h, h->P, (size_t)2 * Npad * ldp * 8))) return rc;
   if ((rc = ensure(h, h->YT, (size_t)RHS_ROWS * ld * 8))) return rc;
   if ((rc = ensure(h, h->scalars, 64))) return rc;
   if ((rc = ensure(h, h->info, 64))) return rc;
@@ -356,8 +406,8 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
     }
     {
       PhaseScope ps(h, &tm.chol);
-      chol_enqueue(h, dK, ld, Npad, h->nb, (double*)h->Winv.p, (double*)h->P.p, ldp, dInfo, 0,
-                   profile);
+      chol_enqueue(h, dK, ld, Npad, h->nb, (double*)h->Winv.p, (double*)h->P.p,
+                   (double*)h->P.p + Npad * ldp, ldp, dInfo, 0, profile);
     }
     {
       PhaseScope ps(h, &tm.solve);
@@ -489,13 +539,15 @@ struct Scratch {  // a throw-away handle-like context for the host-buffer entry 
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
     h.cfg.device = dev;
-    ok = hipStreamCreateWithFlags(&h.st, hipStreamNonBlocking) == hipSuccess;
+    ok = hipStreamCreateWithFlags(&h.st, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&h.st2, hipStreamNonBlocking) == hipSuccess;
   }
   ~Scratch() {
-    if (h.st) {
-      (void)hipStreamSynchronize(h.st);
-      (void)hipStreamDestroy(h.st);
-    }
+    for (hipStream_t s : {h.st, h.st2})
+      if (s) {
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamDestroy(s);
+      }
     for (auto e : h.ev_pool) (void)hipEventDestroy(e);
   }
 };
@@ -567,11 +619,11 @@ int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info) {
   int rc = GPX_OK;
   TCHK(hipMalloc(&dA, (size_t)n * ld * 8));
   TCHK(hipMalloc(&dW, (size_t)(n / 64) * 4096 * 8));
-  TCHK(hipMalloc(&dP, (size_t)n * ldp * 8));
+  TCHK(hipMalloc(&dP, (size_t)2 * n * ldp * 8));
   TCHK(hipMalloc(&dInfo, 64));
   TCHK(hipMemcpy2DAsync(dA, (size_t)ld * 8, A, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice, st));
   TCHK(hipMemcpyAsync(dInfo, &hinfo, sizeof(int), hipMemcpyHostToDevice, st));
-  chol_enqueue(&sc.h, dA, ld, n, nb, dW, dP, ldp, dInfo, 0, false);
+  chol_enqueue(&sc.h, dA, ld, n, nb, dW, dP, dP + n * ldp, ldp, dInfo, 0, false);
   TCHK(hipMemcpy2DAsync(A, (size_t)n * 8, dA, (size_t)ld * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost, st));
   TCHK(hipMemcpyAsync(&hinfo, dInfo, sizeof(int), hipMemcpyDeviceToHost, st));
   TCHK(hipStreamSynchronize(st));

@@ -134,6 +134,128 @@ __device__ __forceinline__ void gemm_tile(const double* A, int64_t lda, const do
   }
 }
 
+// ---- NT tile engine with LDS-DMA staging ------------------------------------------------
+// acc += A(BM x K) * B(BN x K)^T, both row-major with k contiguous.  Per 16-double
+// k-step every wave issues BM/32 + BN/32 `global_load_lds_dwordx4` (1 KiB = 8 rows x
+// 128 B each, straight into LDS: no staging VGPRs, no ds_write) for step t+1 before the
+// MFMAs of step t; `__syncthreads()` drains them (vmcnt(0)) once per step.
+// LDS image: [row][8 slots of 16 B], physical slot = logical slot ^ swz(row).  LDS-DMA
+// writes lane-linear, so the swizzle is applied to the per-lane SOURCE address and to the
+// fragment reads (cdna_hip_programming.md rule 21).  swz() is chosen so that a
+// ds_read_b128 lane group (rows {0-3,12-15} at k-group g with rows {4-11} at g+1, and the
+// three analogous groups) hits 16 distinct 16-byte bank slots: conflict-free.
+// k permutation: lane group g = l>>4 consumes k = 4g+s at MFMA step s (instead of 4s+g) —
+// the same for A and B, so one ds_read_b128 pair per fragment feeds all four steps.
+__device__ __forceinline__ int swz(int row) {
+  const int t = ((row >> 1) + 2) & 7;
+  return ((t & 3) << 1) | (t >> 2);
+}
+
+template <int BM, int BN>
+struct TileShapeG {
+  static constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK;
+  static constexpr int SMEM_DOUBLES = 2 * (A_STAGE + B_STAGE);
+};
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define GPX_GLDS16(gptr, lptr)                                                               \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),    \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_tile_g(const double* A, int64_t lda, const double* B,
+                                            int64_t ldb, int K, v4d (&acc)[BM / 32][BN / 32],
+                                            double* smem) {
+  using S = TileShapeG<BM, BN>;
+  constexpr int MT = BM / 32, NT = BN / 32, WM = BM / 2, WN = BN / 2;
+  constexpr int IA = BM / 32, IB = BN / 32;  // DMA instructions per wave per k-step
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  double* As = smem;
+  double* Bs = smem + 2 * S::A_STAGE;
+
+  // DMA: instruction q of this wave covers rows 8*(wave*I + q) .. +7; lane -> (row, slot)
+  const int drow = lane >> 3, dslot = lane & 7;
+  const double* ga[IA];
+  const double* gb[IB];
+#pragma unroll
+  for (int q = 0; q < IA; ++q) {
+    const int row = (wave * IA + q) * 8 + drow;
+    ga[q] = A + (int64_t)row * lda + ((dslot ^ swz(row)) << 1);
+  }
+#pragma unroll
+  for (int q = 0; q < IB; ++q) {
+    const int row = (wave * IB + q) * 8 + drow;
+    gb[q] = B + (int64_t)row * ldb + ((dslot ^ swz(row)) << 1);
+  }
+  double* const la = As + wave * IA * 128;  // wave-uniform LDS destinations (doubles)
+  double* const lb = Bs + wave * IB * 128;
+
+  // fragment reads: row = w*W + t*16 + l15, logical slots 2*l4 and 2*l4+1
+  const int sw = swz(l15);
+  const int a_off0 = (wr * WM + l15) * BK + (((2 * l4) ^ sw) << 1);
+  const int a_off1 = (wr * WM + l15) * BK + (((2 * l4 + 1) ^ sw) << 1);
+  const int b_off0 = (wc * WN + l15) * BK + (((2 * l4) ^ sw) << 1);
+  const int b_off1 = (wc * WN + l15) * BK + (((2 * l4 + 1) ^ sw) << 1);
+
+#pragma unroll
+  for (int q = 0; q < IA; ++q) GPX_GLDS16(ga[q], la + q * 128);
+#pragma unroll
+  for (int q = 0; q < IB; ++q) GPX_GLDS16(gb[q], lb + q * 128);
+  __syncthreads();
+
+  const int KT = K / BK;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) {
+      const int64_t ko = (int64_t)(kt + 1) * BK;
+#pragma unroll
+      for (int q = 0; q < IA; ++q) GPX_GLDS16(ga[q] + ko, la + (buf ^ 1) * S::A_STAGE + q * 128);
+#pragma unroll
+      for (int q = 0; q < IB; ++q) GPX_GLDS16(gb[q] + ko, lb + (buf ^ 1) * S::B_STAGE + q * 128);
+    }
+    const double* Ab = As + buf * S::A_STAGE;
+    const double* Bb = Bs + buf * S::B_STAGE;
+    v2d a0[MT], b0[NT], a1[MT], b1[NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a0[m] = *reinterpret_cast<const v2d*>(Ab + a_off0 + m * 16 * BK);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b0[n] = *reinterpret_cast<const v2d*>(Bb + b_off0 + n * 16 * BK);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a1[m] = *reinterpret_cast<const v2d*>(Ab + a_off1 + m * 16 * BK);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b1[n] = *reinterpret_cast<const v2d*>(Bb + b_off1 + n * 16 * BK);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[m].x, b0[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[m].y, b0[n].y, acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[m].x, b1[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[m].y, b1[n].y, acc[m][n], 0, 0, 0);
+    // keep the MFMAs ABOVE the barrier: hipcc otherwise sinks them below the vmcnt(0)
+    // drain of __syncthreads() and the DMA latency is exposed on every k-step
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void zero_acc(v4d (&acc)[MT][NT]) {
 #pragma unroll
@@ -190,24 +312,47 @@ __device__ __forceinline__ void tri_coords(int64_t t, int& ti, int& tj) {
   tj = (int)(t - i * (i + 1) / 2);
 }
 
+// Logical tile order: 8x8 super-tiles (64 tiles = what one XCD runs concurrently at 2
+// workgroups per CU), so the tiles in flight on an XCD share 8 A row-slices and 8 B
+// row-slices through its L2 instead of re-fetching the panel per tile.
+//   TRI : super-tiles enumerate the lower triangle of the super-tile grid (m == n);
+//         slots above the diagonal exit at once (<= 3 % of the grid at T >= 64).
+//   !TRI: rectangular super-tile grid (sh x 64/sh tiles each); mask_lower != 0 also
+//         drops tiles with tj > ti (look-ahead strip of the SYRK).
+template <bool TRI>
+__device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, int tiles_n, int sh,
+                                            int mask_lower, int& ti, int& tj) {
+  const int64_t st = lin >> 6;
+  const int inner = (int)(lin & 63);
+  if (TRI) {
+    int sr, sc;
+    tri_coords(st, sr, sc);
+    ti = sr * 8 + (inner >> 3);
+    tj = sc * 8 + (inner & 7);
+    return ti < tiles_m && tj <= ti;
+  } else {
+    const int sw = 64 / sh;                       // sh in {1, 8}
+    const int sn = (tiles_n + sw - 1) / sw;
+    const int sr = (int)(st / sn), sc = (int)(st - (int64_t)sr * sn);
+    ti = sr * sh + inner / sw;
+    tj = sc * sw + inner % sw;
+    return ti < tiles_m && tj < tiles_n && (!mask_lower || tj <= ti);
+  }
+}
+
 // ---- C op= A * B^T --------------------------------------------------------------
-template <int BT, bool LOWER, int MODE>
-__global__ __launch_bounds__(256, (BT == 128 ? 2 : 2)) void gemm_nt_kernel(
+template <int BT, bool TRI, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     double* __restrict__ C, int64_t ldc, const double* __restrict__ A, int64_t lda,
-    const double* __restrict__ B, int64_t ldb, int tiles_m, int K) {
-  __shared__ __attribute__((aligned(16))) double smem[TileShape<BT, BT, false>::SMEM_DOUBLES];
+    const double* __restrict__ B, int64_t ldb, int tiles_m, int tiles_n, int sh, int mask_lower,
+    int K) {
+  __shared__ __attribute__((aligned(16))) double smem[TileShapeG<BT, BT>::SMEM_DOUBLES];
   const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
   int ti, tj;
-  if (LOWER) {
-    tri_coords(lin, ti, tj);
-  } else {
-    // consecutive ids walk down a column of tiles: they share the B rows
-    tj = (int)(lin / tiles_m);
-    ti = (int)(lin - (int64_t)tj * tiles_m);
-  }
+  if (!tile_coords<TRI>(lin, tiles_m, tiles_n, sh, mask_lower, ti, tj)) return;
   v4d acc[BT / 32][BT / 32];
   zero_acc(acc);
-  gemm_tile<BT, BT, false>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K,
+  gemm_tile_g<BT, BT>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K,
                            acc, smem);
   store_tile<BT, BT, MODE>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
 }
@@ -216,11 +361,11 @@ __global__ __launch_bounds__(256, (BT == 128 ? 2 : 2)) void gemm_nt_kernel(
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(double* __restrict__ C, int64_t ldc,
                                                          const double* __restrict__ A, int64_t lda,
                                                          const double* __restrict__ B, int64_t ldb,
-                                                         int tiles_m, int K) {
+                                                         int tiles_m, int tiles_n, int sh, int K) {
   __shared__ __attribute__((aligned(16))) double smem[TileShape<64, 64, true>::SMEM_DOUBLES];
   const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
-  const int tj = (int)(lin / tiles_m);
-  const int ti = (int)(lin - (int64_t)tj * tiles_m);
+  int ti, tj;
+  if (!tile_coords<false>(lin, tiles_m, tiles_n, sh, 0, ti, tj)) return;
   v4d acc[2][2];
   zero_acc(acc);
   gemm_tile<64, 64, true>(A + (int64_t)ti * 64 * lda, lda, B + (int64_t)tj * 64, ldb, K, acc,
@@ -229,56 +374,183 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(double* __restrict__ C,
 }
 
 // ---- POTF2 of one 64x64 block + explicit inverse -------------------------------------
-// Right-looking column Cholesky in LDS (one barrier per column), then the inverse of
-// the factor row by row (W L = I), both fp64.  A non-positive / NaN pivot records
-// (global index + 1) in *info by atomicMin and lets NaN propagate (LAPACK potrf info).
-constexpr int PLD = 65;
+// One workgroup, everything in LDS.  Factorisation in 16 steps of 4 columns:
+//   phase A  every thread factors the 4x4 diagonal block redundantly in registers
+//            (rsqrt-based, no divisions); thread i < 64 solves its row of the 4-column
+//            panel and drops it in PB[64][4];
+//   phase B  the rank-4 trailing update C -= PB PB^T is ONE v_mfma_f64_16x16x4_f64 per
+//            16x16 tile (<= 10 lower tiles over 4 waves); columns already final are
+//            masked through a zero B operand and predicated stores.
+// Inverse W = L^-1 by recursive blocking: four 16x16 diagonal inverses (one column per
+// lane, reciprocal pivots reused from the factorisation), then W21 = -W22 (L21 W11) at
+// 32 and at 64 with MFMA products through a small LDS scratch tile.
+// LDS: 2 x 64x66 + scratch = 77 KB — fits the slot of one retiring SYRK workgroup (73.7
+// KB + 16 KB spare per CU), which lets the look-ahead stream run beside the trailing
+// update; s_setprio(3) keeps its waves ahead of the co-resident SYRK waves.
+// A non-positive / NaN pivot records (global index + 1) in *info by atomicMin and lets
+// NaN propagate (LAPACK potrf info convention).
+constexpr int PLD = 66;
+constexpr int TLD = 34;
+
+__device__ __forceinline__ v4d mfma0(double a, double b) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, (v4d){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+}
+
 __global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, int64_t lda,
                                                        double* __restrict__ Winv, int64_t gidx0,
                                                        int* __restrict__ info) {
-  __shared__ double Wk[64 * PLD];
-  __shared__ double Lo[64 * PLD];
-  __shared__ double Wi[64 * PLD];
+  __shared__ __attribute__((aligned(16))) double Wk[64 * PLD];  // working matrix -> L (lower)
+  __shared__ __attribute__((aligned(16))) double Wi[64 * PLD];  // inverse
+  __shared__ __attribute__((aligned(16))) double PB[64 * 4];    // current 4-column panel
+  __shared__ __attribute__((aligned(16))) double Tm[32 * TLD];  // product scratch
+  __shared__ double Rinv[64];                                    // 1 / L[i][i]
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
   for (int e = tid; e < 4096; e += 256) {
     const int i = e >> 6, k = e & 63;
     Wk[i * PLD + k] = (k <= i) ? A[(int64_t)i * lda + k] : 0.0;
-    Lo[i * PLD + k] = 0.0;
     Wi[i * PLD + k] = 0.0;
   }
   __syncthreads();
-  const int i = tid >> 2, part = tid & 3;
-  for (int j = 0; j < 64; ++j) {
-    const double ajj = Wk[j * PLD + j];
-    if (!(ajj > 0.0) && tid == 0) atomicMin(info, (int)(gidx0 + j + 1));
-    const double dj = sqrt(ajj);
-    const double inv = 1.0 / dj;
-    if (i > j) {
-      const double lij = Wk[i * PLD + j] * inv;
-      if (part == 0) Lo[i * PLD + j] = lij;
-      for (int k = j + 1 + part; k <= i; k += 4) {
-        const double lkj = Wk[k * PLD + j] * inv;
-        Wk[i * PLD + k] -= lij * lkj;
+
+  for (int j = 0; j < 64; j += 4) {
+    // ---- phase A: 4x4 diagonal factor (redundant per thread) + this thread's panel row
+    const double* D = Wk + j * PLD + j;
+    const double a00 = D[0];
+    const double a10 = D[PLD], a11 = D[PLD + 1];
+    const double a20 = D[2 * PLD], a21 = D[2 * PLD + 1], a22 = D[2 * PLD + 2];
+    const double a30 = D[3 * PLD], a31 = D[3 * PLD + 1], a32 = D[3 * PLD + 2], a33 = D[3 * PLD + 3];
+    const double rs0 = rsqrt(a00);
+    const double l10 = a10 * rs0, l20 = a20 * rs0, l30 = a30 * rs0;
+    const double b11 = a11 - l10 * l10;
+    const double rs1 = rsqrt(b11);
+    const double l21 = (a21 - l20 * l10) * rs1, l31 = (a31 - l30 * l10) * rs1;
+    const double b22 = a22 - l20 * l20 - l21 * l21;
+    const double rs2 = rsqrt(b22);
+    const double l32 = (a32 - l30 * l20 - l31 * l21) * rs2;
+    const double b33 = a33 - l30 * l30 - l31 * l31 - l32 * l32;
+    const double rs3 = rsqrt(b33);
+    if (tid == 0) {
+      const int bad = !(a00 > 0.0) ? 1 : !(b11 > 0.0) ? 2 : !(b22 > 0.0) ? 3 : !(b33 > 0.0) ? 4 : 0;
+      if (bad) atomicMin(info, (int)(gidx0 + j + bad));
+      Rinv[j] = rs0;
+      Rinv[j + 1] = rs1;
+      Rinv[j + 2] = rs2;
+      Rinv[j + 3] = rs3;
+    }
+    if (tid < 64) {
+      const int i = tid;
+      double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+      if (i >= j) {
+        const double* row = Wk + i * PLD + j;
+        x0 = row[0] * rs0;
+        x1 = (row[1] - x0 * l10) * rs1;
+        x2 = (row[2] - x0 * l20 - x1 * l21) * rs2;
+        x3 = (row[3] - x0 * l30 - x1 * l31 - x2 * l32) * rs3;
+        const int c = i - j;  // rows of the diagonal block: strictly-upper part is zero
+        if (c < 1) x1 = 0.0;
+        if (c < 2) x2 = 0.0;
+        if (c < 3) x3 = 0.0;
       }
-    } else if (i == j && part == 0) {
-      Lo[j * PLD + j] = dj;
+      PB[i * 4 + 0] = x0;
+      PB[i * 4 + 1] = x1;
+      PB[i * 4 + 2] = x2;
+      PB[i * 4 + 3] = x3;
     }
     __syncthreads();
-  }
-  // inverse: row r of W from rows < r
-  const int c = i;
-  for (int r = 0; r < 64; ++r) {
-    double s = 0.0;
-    if (c <= r)
-      for (int k = c + part; k < r; k += 4) s += Lo[r * PLD + k] * Wi[k * PLD + c];
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if (c <= r && part == 0) Wi[r * PLD + c] = ((c == r ? 1.0 : 0.0) - s) / Lo[r * PLD + r];
+    // ---- phase B: commit the panel, rank-4 update of the trailing lower tiles
+    if (tid < 64 && tid >= j) {
+      double* row = Wk + tid * PLD + j;
+      row[0] = PB[tid * 4 + 0];
+      row[1] = PB[tid * 4 + 1];
+      row[2] = PB[tid * 4 + 2];
+      row[3] = PB[tid * 4 + 3];
+    }
+    const int jn = j + 4;
+    const int t0 = jn >> 4;
+    int idx = 0;
+    for (int tr = t0; tr < 4; ++tr)
+      for (int tc = t0; tc <= tr; ++tc, ++idx) {
+        if ((idx & 3) != wave) continue;
+        const int colg = tc * 16 + l15;
+        const double a = PB[(tr * 16 + l15) * 4 + l4];
+        const double b = (colg >= jn) ? PB[colg * 4 + l4] : 0.0;
+        const v4d acc = mfma0(a, b);
+        if (colg >= jn) {
+          double* Cp = Wk + (tr * 16 + l4) * PLD + colg;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cp[4 * r * PLD] -= acc[r];
+        }
+      }
     __syncthreads();
   }
+
+  // ---- inverse, level 0: wave w inverts diagonal block w; lane c < 16 owns column c
+  {
+    const int b0 = wave * 16;
+    if (lane < 16) {
+      double w[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) sacc -= Wk[(b0 + i) * PLD + b0 + k] * w[k];
+        w[i] = sacc * Rinv[b0 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Wi[(b0 + i) * PLD + b0 + lane] = w[i];
+    }
+  }
+  __syncthreads();
+  // ---- level 1: blocks (1,0) on wave 0 and (3,2) on wave 1:  W10 = -W11 (L10 W00)
+  if (wave < 2) {
+    const int c0 = wave * 32, r1 = c0 + 16;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wk[(r1 + l15) * PLD + c0 + ks * 4 + l4],
+                                                 Wi[(c0 + ks * 4 + l4) * PLD + c0 + l15], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tm[(wave * 16 + l4 + 4 * r) * TLD + l15] = acc[r];
+  }
+  __syncthreads();
+  if (wave < 2) {
+    const int c0 = wave * 32, r1 = c0 + 16;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wi[(r1 + l15) * PLD + r1 + ks * 4 + l4],
+                                                 Tm[(wave * 16 + ks * 4 + l4) * TLD + l15], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wi[(r1 + l4 + 4 * r) * PLD + c0 + l15] = -acc[r];
+  }
+  __syncthreads();
+  // ---- level 2: W_BA = -W_BB (L_BA W_AA), 32x32 blocks, one 16x16 tile per wave
+  {
+    const int tr = wave >> 1, tc = wave & 1;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wk[(32 + tr * 16 + l15) * PLD + ks * 4 + l4],
+                                                 Wi[(ks * 4 + l4) * PLD + tc * 16 + l15], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tm[(tr * 16 + l4 + 4 * r) * TLD + tc * 16 + l15] = acc[r];
+    __syncthreads();
+    v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Wi[(32 + tr * 16 + l15) * PLD + 32 + ks * 4 + l4],
+                                                  Tm[(ks * 4 + l4) * TLD + tc * 16 + l15], acc2, 0, 0, 0);
+    __syncthreads();  // every read of W_BB / Tm done before W_BA lands next to them
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wi[(32 + tr * 16 + l4 + 4 * r) * PLD + tc * 16 + l15] = -acc2[r];
+  }
+  __syncthreads();
   for (int e = tid; e < 4096; e += 256) {
     const int ii = e >> 6, k = e & 63;
-    if (k <= ii) A[(int64_t)ii * lda + k] = Lo[ii * PLD + k];
+    if (k <= ii) A[(int64_t)ii * lda + k] = Wk[ii * PLD + k];
     Winv[e] = Wi[ii * PLD + k];
   }
 }
@@ -293,7 +565,8 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(double* __restrict__ A, i
 __global__ __launch_bounds__(256, 2) void trsm_rlt_kernel(double* X, int64_t ldx, const double* L,
                                                           int64_t ldl, const double* Winv, int nbq,
                                                           double* P, int64_t ldp) {
-  __shared__ __attribute__((aligned(16))) double smem[TileShape<64, 64, false>::SMEM_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double smem[TileShapeG<64, 64>::SMEM_DOUBLES];
+  __builtin_amdgcn_s_setprio(2);  // panel solve is on the critical path of the look-ahead
   double* Xs = X + (int64_t)blockIdx.x * 64 * ldx;
   double* Ps = P ? P + (int64_t)blockIdx.x * 64 * ldp : nullptr;
   v4d acc[2][2];
@@ -301,12 +574,12 @@ __global__ __launch_bounds__(256, 2) void trsm_rlt_kernel(double* X, int64_t ldx
     double* Xj = Xs + jb * 64;
     if (jb > 0) {
       zero_acc(acc);
-      gemm_tile<64, 64, false>(Xs, ldx, L + (int64_t)jb * 64 * ldl, ldl, jb * 64, acc, smem);
+      gemm_tile_g<64, 64>(Xs, ldx, L + (int64_t)jb * 64 * ldl, ldl, jb * 64, acc, smem);
       store_tile<64, 64, 0>(Xj, ldx, acc);
       __syncthreads();
     }
     zero_acc(acc);
-    gemm_tile<64, 64, false>(Xj, ldx, Winv + (int64_t)jb * 4096, 64, 64, acc, smem);
+    gemm_tile_g<64, 64>(Xj, ldx, Winv + (int64_t)jb * 4096, 64, 64, acc, smem);
     // gemm_tile ends with a barrier: every read of T is complete
     store_tile<64, 64, 1>(Xj, ldx, acc);
     if (Ps) store_tile<64, 64, 1>(Ps + jb * 64, ldp, acc);
@@ -357,23 +630,33 @@ void launch_trsm_rln(double* X, int64_t ldx, int64_t rows, const double* L, int6
                      Winv, nb / 64);
 }
 
+static int64_t rect_grid(int64_t tm, int64_t tn, int& sh) {
+  sh = tm >= 8 ? 8 : 1;
+  const int sw = 64 / sh;
+  return ((tm + sh - 1) / sh) * ((tn + sw - 1) / sw) * 64;
+}
+
 template <int BT>
 static void launch_gemm_nt_t(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                              int64_t ldb, int64_t m, int64_t n, int64_t k, int lower, int mode,
                              hipStream_t st) {
   const int64_t tm = m / BT, tn = n / BT;
-  const int64_t nblk = lower ? tm * (tm + 1) / 2 : tm * tn;
-  dim3 grid((unsigned)nblk), block(256);
-  if (lower) {
+  dim3 block(256);
+  if (lower == 1) {  // full lower triangle, triangular super-tile enumeration
+    const int64_t ts = (tm + 7) / 8;
+    dim3 grid((unsigned)(ts * (ts + 1) / 2 * 64));
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<BT, true, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<BT, true, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<BT, true, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)k);
-  } else {
+      hipLaunchKernelGGL((gemm_nt_kernel<BT, true, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, (int)k);
+  } else {           // rectangle; lower == 2: masked to tj <= ti
+    int sh;
+    dim3 grid((unsigned)rect_grid(tm, tn, sh));
+    const int mask = lower == 2 ? 1 : 0;
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<BT, false, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<BT, false, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<BT, false, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<BT, false, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, (int)k);
   }
 }
 
@@ -391,8 +674,10 @@ void launch_gemm_nn(double* C, int64_t ldc, const double* A, int64_t lda, const 
                     int64_t ldb, int64_t m, int64_t n, int64_t k, hipStream_t st) {
   if (m <= 0 || n <= 0) return;
   const int64_t tm = m / 64, tn = n / 64;
-  hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)(tm * tn)), dim3(256), 0, st, C, ldc, A, lda, B,
-                     ldb, (int)tm, (int)k);
+  int sh;
+  const int64_t nblk = rect_grid(tm, tn, sh);
+  hipLaunchKernelGGL(gemm_nn_kernel, dim3((unsigned)nblk), dim3(256), 0, st, C, ldc, A, lda, B,
+                     ldb, (int)tm, (int)tn, sh, (int)k);
 }
 
 }  // namespace gpx

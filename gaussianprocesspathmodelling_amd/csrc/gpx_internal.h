@@ -40,7 +40,8 @@ void launch_trsm_rln(double* X, int64_t ldx, int64_t rows, const double* L, int6
                      const double* Winv, int nb, hipStream_t st);
 // C (m x n, ldc) op= A (m x k, lda) * B (n x k, ldb)^T.
 //   mode 0: C -= A B^T      mode 1: C = A B^T
-//   lower != 0: only tiles with tile_col <= tile_row (m == n).
+//   lower 0: every tile;  1: lower triangle (m == n), triangular super-tile order;
+//         2: rectangle masked to tile_col <= tile_row (look-ahead strip).
 //   tile = 128 (m,n multiples of 128) or 64 (multiples of 64); k multiple of 16.
 void launch_gemm_nt(int tile, double* C, int64_t ldc, const double* A, int64_t lda,
                     const double* B, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower,

@@ -70,7 +70,7 @@ typedef struct gpx_timings {
   double kstar, mean, trsm, var, d2h, predict_total;           /* gpx_predict */
   double comm;                                                 /* RCCL time inside chol (sharded) */
   /* Cholesky sub-phases, filled only with GPX_FLAG_PROFILE: */
-  double chol_diag, chol_trsm, chol_syrk;  /* summed ms                          */
+  double chol_diag, chol_trsm, chol_strip, chol_syrk; /* summed ms (diag/trsm run on the look-ahead stream) */
   double syrk_flops;                       /* algorithmic flops of all SYRK launches: n(n+1) nb each */
   int64_t syrk_launches;
   double kbuild_bytes;                     /* algorithmic bytes of the kernel build */
