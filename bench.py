@@ -163,7 +163,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C3: exact GP fit+predict, N={N} d={DIM} RBF fp64, M={M}, "
                                    f"inputs resident in HBM", "N": N, "d": DIM, "M": M,
-                       "kernel": KERNEL, "block": args.block or 512,
+                       "kernel": KERNEL, "block": args.block or 1024,
                        "parallelism": "1 gpu" if world == 1 else f"{world} independent replicas"},
             "outputs_finite": ok,
             "phases_ms": phases,

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -50,7 +51,9 @@ struct DevBuf {
 
 struct gpx_handle {
   gpx_config cfg{};
-  int nb = 512;
+  int nb = 1024;       // Cholesky panel width
+  int nb_solve = 256;  // block width of the alpha solves (one 64-row slab: latency-bound)
+  int nb_pred = 1024;  // block width of the variance TRSM
   hipStream_t st = nullptr;   // main stream
   hipStream_t st2 = nullptr;  // look-ahead (panel) stream, high priority
   std::string err;
@@ -302,9 +305,9 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
     return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: only GPX_F64 is implemented");
   if (cfg->world != 1 || cfg->rank != 0)
     return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: sharded (world > 1) handles not implemented yet");
-  const int nb = cfg->block == 0 ? 512 : cfg->block;
-  if (nb < 128 || nb > 1024 || nb % 128 != 0)
-    return fail(nullptr, GPX_E_ARG, "gpx_create: block must be a multiple of 128 in [128, 1024]");
+  const int nb = cfg->block == 0 ? 1024 : cfg->block;
+  if (nb < 128 || nb > 2048 || nb % 128 != 0)
+    return fail(nullptr, GPX_E_ARG, "gpx_create: block must be a multiple of 128 in [128, 2048]");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, GPX_E_HIP, "gpx_create: no HIP device visible (libgpx has no CPU fallback)");
@@ -314,6 +317,8 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
   if (!h) return fail(nullptr, GPX_E_NOMEM, "gpx_create: out of host memory");
   h->cfg = *cfg;
   h->nb = nb;
+  if (const char* e = getenv("GPX_NB_SOLVE")) h->nb_solve = atoi(e);
+  if (const char* e = getenv("GPX_NB_PRED")) h->nb_pred = atoi(e);
   int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(cfg->device) != hipSuccess ||
       hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
@@ -412,8 +417,8 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
     {
       PhaseScope ps(h, &tm.solve);
       launch_pack_rhs((const double*)h->Y.p, N, k, dYT, ld, Npad, RHS_ROWS, h->st);
-      solve_fwd_enqueue(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb, (const double*)h->Winv.p);
-      solve_bwd_enqueue(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb, (const double*)h->Winv.p);
+      solve_fwd_enqueue(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const double*)h->Winv.p);
+      solve_bwd_enqueue(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const double*)h->Winv.p);
     }
     {
       PhaseScope ps(h, &tm.logdet);
@@ -476,7 +481,7 @@ int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var,
     if (var) {
       {
         PhaseScope ps(h, &tm.trsm);
-        solve_fwd_enqueue(h, dVT, Mpad, dK, ld, Npad, h->nb, dWinv);
+        solve_fwd_enqueue(h, dVT, Mpad, dK, ld, Npad, h->nb_pred, dWinv);
       }
       {
         PhaseScope ps(h, &tm.var);
@@ -607,7 +612,7 @@ done:
 
 int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info) {
   if (!A || !info || n <= 0 || n % 64 != 0) return GPX_E_ARG;
-  const int nb = block == 0 ? 512 : block;
+  const int nb = block == 0 ? 1024 : block;
   if (nb % 128 != 0 || nb < 128) return GPX_E_ARG;
   Scratch sc;
   if (!sc.ok) return GPX_E_HIP;

@@ -17,6 +17,8 @@
 //
 // fp64 MFMA layouts (cdna_hip_programming.md §3): A lane l = A[l&15][l>>4],
 // B lane l = B[l>>4][l&15], D reg r of lane l = D[(l>>4) + 4r][l&15].
+#include <cstdlib>
+
 #include "gpx_internal.h"
 
 namespace gpx {

@@ -56,7 +56,7 @@ typedef struct gpx_config {
   int32_t kernel;  /* GPX_KERNEL_*                                   */
   int32_t dtype;   /* GPX_F64 | GPX_F32                              */
   int32_t device;  /* HIP device ordinal this handle computes on     */
-  int32_t block;   /* Cholesky panel width nb (multiple of 128), 0 = default (512) */
+  int32_t block;   /* Cholesky panel width nb (multiple of 128, <= 2048), 0 = default (1024) */
   int32_t rank;    /* this process' rank in the row-block shard (0 if world==1)    */
   int32_t world;   /* number of GPUs sharing the Gram matrix (1 = unsharded)       */
   int32_t flags;   /* GPX_FLAG_*                                     */
