@@ -35,6 +35,18 @@ class GpxTimings(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+# gpx_host_comm: host-buffer collectives supplied by the caller (tests / non-RCCL fabrics)
+BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+
+
+class GpxHostComm(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("bcast", BCAST_FN), ("allgather", ALLGATHER_FN),
+                ("reduce", REDUCE_FN), ("allreduce", ALLREDUCE_FN)]
+
+
 # every symbol include/gpx.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _PD = C.POINTER(C.c_double)
@@ -52,6 +64,7 @@ SIGNATURES = {
     "gpx_get_timings": (C.c_int, [_P, C.POINTER(GpxTimings)]),
     "gpx_comm_unique_id": (C.c_int, [_P]),
     "gpx_comm_init": (C.c_int, [_P, _P]),
+    "gpx_comm_init_host": (C.c_int, [_P, C.POINTER(GpxHostComm)]),
     "gpx_kernel_matrix": (C.c_int, [C.c_int32, _PD, C.c_int64, _PD, C.c_int64, C.c_int32, _PD,
                                     C.c_int32, C.c_double, C.c_double, _PD]),
     "gpx_potrf": (C.c_int, [_PD, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),

@@ -47,6 +47,8 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+struct Comm;  // gpx_shard.inc
+
 }  // namespace
 
 struct gpx_handle {
@@ -67,6 +69,11 @@ struct gpx_handle {
   DevBuf X, Xs, ls, K, Winv, P, YT, Y, scalars, info;
   // predict state
   DevBuf Q, Qs, VT, MT, var, meanout;
+  // row-block shard (world > 1)
+  Comm* comm = nullptr;  // RCCL or host-callback transport (gpx_shard.inc)
+  int nb_shard = 512;  // distribution block = panel width of the sharded factorisation
+  int64_t nloc = 0, ldy = 0;
+  DevBuf G, Pglob, Dbuf, Sbuf, YTloc, Cneg, Sv;
   // event pool
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -279,6 +286,8 @@ int copy_out(gpx_handle* h, void* dst, const void* src, size_t bytes, int mem_ki
 
 }  // namespace
 
+#include "gpx_shard.inc"
+
 extern "C" {
 
 int gpx_abi_version(void) { return GPX_ABI_VERSION; }
@@ -303,8 +312,8 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
     return fail(nullptr, GPX_E_ARG, "gpx_create: unknown kernel id");
   if (cfg->dtype != GPX_F64)
     return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: only GPX_F64 is implemented");
-  if (cfg->world != 1 || cfg->rank != 0)
-    return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: sharded (world > 1) handles not implemented yet");
+  if (cfg->world < 1 || cfg->world > 64 || cfg->rank < 0 || cfg->rank >= cfg->world)
+    return fail(nullptr, GPX_E_ARG, "gpx_create: need 1 <= world <= 64 and 0 <= rank < world");
   const int nb = cfg->block == 0 ? 1024 : cfg->block;
   if (nb < 128 || nb > 2048 || nb % 128 != 0)
     return fail(nullptr, GPX_E_ARG, "gpx_create: block must be a multiple of 128 in [128, 2048]");
@@ -317,6 +326,8 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
   if (!h) return fail(nullptr, GPX_E_NOMEM, "gpx_create: out of host memory");
   h->cfg = *cfg;
   h->nb = nb;
+  if (const char* e = getenv("GPX_NB_SHARD")) h->nb_shard = atoi(e);
+  if (h->nb_shard < 128 || h->nb_shard > 2048 || h->nb_shard % 128 != 0) h->nb_shard = 512;
   if (const char* e = getenv("GPX_NB_SOLVE")) h->nb_solve = atoi(e);
   if (const char* e = getenv("GPX_NB_PRED")) h->nb_pred = atoi(e);
   int prio_lo = 0, prio_hi = 0;
@@ -338,8 +349,10 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st) (void)hipStreamSynchronize(h->st);
   if (h->st2) (void)hipStreamSynchronize(h->st2);
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
-                    &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout})
+                    &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout, &h->G, &h->Pglob,
+                    &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv})
     release(*b);
+  destroy_comm(h);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->st) (void)hipStreamDestroy(h->st);
   if (h->st2) (void)hipStreamDestroy(h->st2);
@@ -364,6 +377,8 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->fitted = false;
   h->err.clear();
+  if (h->cfg.world > 1 || h->comm)  // a 1-rank communicator also takes the sharded schedule
+    return shard_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
 
   const int64_t Npad = round_up(N, TILE);
   const int64_t ld = Npad + LD_SKEW;
@@ -444,6 +459,7 @@ int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var,
     return fail(h, GPX_E_ARG, "gpx_predict: bad mem_kind");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->err.clear();
+  if (h->cfg.world > 1 || h->comm) return shard_predict(h, Xq, M, mean, var, mem_kind);
   const int64_t N = h->N, Npad = h->Npad, ld = h->ld;
   const int d = h->d, k = h->k;
   const int64_t Mpad = round_up(M, TILE);
@@ -523,16 +539,6 @@ int gpx_get_timings(gpx_handle* h, gpx_timings* out) {
   if (!h || !out) return GPX_E_ARG;
   *out = h->tm;
   return GPX_OK;
-}
-
-int gpx_comm_unique_id(void* id128) {
-  (void)id128;
-  return GPX_E_UNSUPPORTED;
-}
-
-int gpx_comm_init(gpx_handle* h, const void* id128) {
-  (void)id128;
-  return fail(h, GPX_E_UNSUPPORTED, "gpx_comm_init: sharded handles not implemented yet");
 }
 
 // ---- kernel unit-test entry points -------------------------------------------------------

@@ -321,9 +321,14 @@ __device__ __forceinline__ void tri_coords(int64_t t, int& ti, int& tj) {
 //         slots above the diagonal exit at once (<= 3 % of the grid at T >= 64).
 //   !TRI: rectangular super-tile grid (sh x 64/sh tiles each); mask_lower != 0 also
 //         drops tiles with tj > ti (look-ahead strip of the SYRK).
+struct BcMask {   // block-cyclic row map of the sharded trailing update (P == 0: unused)
+  int P, tpb, c;  // global row tile (relative to the trailing start) of local row tile ti:
+                  //   ((ti / tpb) * P + c) * tpb + ti % tpb
+};
+
 template <bool TRI>
 __device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, int tiles_n, int sh,
-                                            int mask_lower, int& ti, int& tj) {
+                                            int mask_lower, const BcMask& bc, int& ti, int& tj) {
   const int64_t st = lin >> 6;
   const int inner = (int)(lin & 63);
   if (TRI) {
@@ -338,7 +343,10 @@ __device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, int tiles_
     const int sr = (int)(st / sn), sc = (int)(st - (int64_t)sr * sn);
     ti = sr * sh + inner / sw;
     tj = sc * sw + inner % sw;
-    return ti < tiles_m && tj < tiles_n && (!mask_lower || tj <= ti);
+    if (ti >= tiles_m || tj >= tiles_n) return false;
+    if (mask_lower == 1) return tj <= ti;
+    if (mask_lower == 2) return tj <= ((ti / bc.tpb) * bc.P + bc.c) * bc.tpb + ti % bc.tpb;
+    return true;
   }
 }
 
@@ -347,11 +355,11 @@ template <int BT, bool TRI, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     double* __restrict__ C, int64_t ldc, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, int tiles_m, int tiles_n, int sh, int mask_lower,
-    int K) {
+    BcMask bc, int K) {
   __shared__ __attribute__((aligned(16))) double smem[TileShapeG<BT, BT>::SMEM_DOUBLES];
   const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
   int ti, tj;
-  if (!tile_coords<TRI>(lin, tiles_m, tiles_n, sh, mask_lower, ti, tj)) return;
+  if (!tile_coords<TRI>(lin, tiles_m, tiles_n, sh, mask_lower, bc, ti, tj)) return;
   v4d acc[BT / 32][BT / 32];
   zero_acc(acc);
   gemm_tile_g<BT, BT>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K,
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(double* __restrict__ C,
   __shared__ __attribute__((aligned(16))) double smem[TileShape<64, 64, true>::SMEM_DOUBLES];
   const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
   int ti, tj;
-  if (!tile_coords<false>(lin, tiles_m, tiles_n, sh, 0, ti, tj)) return;
+  if (!tile_coords<false>(lin, tiles_m, tiles_n, sh, 0, BcMask{0, 1, 0}, ti, tj)) return;
   v4d acc[2][2];
   zero_acc(acc);
   gemm_tile<64, 64, true>(A + (int64_t)ti * 64 * lda, lda, B + (int64_t)tj * 64, ldb, K, acc,
@@ -641,24 +649,24 @@ static int64_t rect_grid(int64_t tm, int64_t tn, int& sh) {
 template <int BT>
 static void launch_gemm_nt_t(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                              int64_t ldb, int64_t m, int64_t n, int64_t k, int lower, int mode,
-                             hipStream_t st) {
+                             BcMask bc, hipStream_t st) {
   const int64_t tm = m / BT, tn = n / BT;
   dim3 block(256);
   if (lower == 1) {  // full lower triangle, triangular super-tile enumeration
     const int64_t ts = (tm + 7) / 8;
     dim3 grid((unsigned)(ts * (ts + 1) / 2 * 64));
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<BT, true, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<BT, true, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<BT, true, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<BT, true, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
   } else {           // rectangle; lower == 2: masked to tj <= ti
     int sh;
     dim3 grid((unsigned)rect_grid(tm, tn, sh));
-    const int mask = lower == 2 ? 1 : 0;
+    const int mask = lower == 2 ? 1 : lower == 3 ? 2 : 0;
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<BT, false, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<BT, false, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<BT, false, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<BT, false, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
   }
 }
 
@@ -666,10 +674,18 @@ void launch_gemm_nt(int tile, double* C, int64_t ldc, const double* A, int64_t l
                     const double* B, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower,
                     int mode, hipStream_t st) {
   if (m <= 0 || n <= 0) return;
+  const BcMask bc{0, 1, 0};
   if (tile == 128)
-    launch_gemm_nt_t<128>(C, ldc, A, lda, B, ldb, m, n, k, lower, mode, st);
+    launch_gemm_nt_t<128>(C, ldc, A, lda, B, ldb, m, n, k, lower, mode, bc, st);
   else
-    launch_gemm_nt_t<64>(C, ldc, A, lda, B, ldb, m, n, k, lower, mode, st);
+    launch_gemm_nt_t<64>(C, ldc, A, lda, B, ldb, m, n, k, lower, mode, bc, st);
+}
+
+void launch_gemm_nt_bc(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                       int64_t ldb, int64_t m, int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c,
+                       hipStream_t st) {
+  if (m <= 0 || n <= 0) return;
+  launch_gemm_nt_t<128>(C, ldc, A, lda, B, ldb, m, n, k, 3, 0, BcMask{bc_P, bc_tpb, bc_c}, st);
 }
 
 void launch_gemm_nn(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,

@@ -46,6 +46,11 @@ void launch_trsm_rln(double* X, int64_t ldx, int64_t rows, const double* L, int6
 void launch_gemm_nt(int tile, double* C, int64_t ldc, const double* A, int64_t lda,
                     const double* B, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower,
                     int mode, hipStream_t st);
+// Sharded trailing update: C (m local rows x n, 128-tiles) -= A B^T restricted to tiles with
+//   tile_col <= ((tile_row / tpb) * P + c) * tpb + tile_row % tpb   (block-cyclic rows).
+void launch_gemm_nt_bc(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                       int64_t ldb, int64_t m, int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c,
+                       hipStream_t st);
 // C (m x n, ldc) -= A (m x k, lda) * B (k x n, ldb); 64x64 tiles.
 void launch_gemm_nn(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                     int64_t ldb, int64_t m, int64_t n, int64_t k, hipStream_t st);
@@ -63,6 +68,25 @@ void launch_var_rows(const double* VT, int64_t ld, int64_t m, int64_t ncols, dou
 // out[0] = 2 * sum_{i<n} log(A[i, i]).
 void launch_logdet(const double* A, int64_t lda, int64_t n, double* out, hipStream_t st);
 void launch_fill(double* p, int64_t count, double v, hipStream_t st);
+// ---- row-block-cyclic shard helpers (gpx_misc.hip) ----------------------------------------
+// A[i][i] = i < nvalid ? A[i][i] + add : 1   for i < n (diagonal of one local row block)
+void launch_fix_diag(double* A, int64_t lda, int n, int nvalid, double add, hipStream_t st);
+// Gathered panel G [P][maxcnt][ldp] (rank-major, each rank's trailing rows in local order)
+// -> Pglob [(nblk-p-1)*nb][ldp] in global row order.
+void launch_unpermute_panel(const double* G, double* Pglob, int64_t ldp, int nb, int P, int p,
+                            int nblk, int64_t maxcnt, hipStream_t st);
+// YTloc[r][lb*nb + i] = y[(g*nb+i)*k + r] for the blocks g = rank + lb*P owned by `rank`.
+void launch_pack_rhs_local(const double* y, int64_t n, int k, double* YTloc, int64_t ldy, int nb,
+                           int nlb, int P, int rank, int R, hipStream_t st);
+// Full[r][g*nb + i] = Loc[r][lb*nb + i] (own blocks), rest untouched.
+void launch_scatter_local(const double* Loc, int64_t ldl, double* Full, int64_t ldf, int nb, int nlb,
+                          int P, int rank, int R, hipStream_t st);
+// dst (rows x cols, ldd) += sign * src (rows x cols, lds)
+void launch_add_block(double* dst, int64_t ldd, const double* src, int64_t lds, int rows, int cols,
+                      double sign, hipStream_t st);
+void launch_add_scalar(double* p, int64_t count, double v, hipStream_t st);
+// out[0] += 2 * sum_i log(A[i][i]), i < n (one diagonal block)
+void launch_logdet_acc(const double* A, int64_t lda, int n, double* out, hipStream_t st);
 void launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st);
 void launch_mfma_loop(double* sink, int iters, int blocks, hipStream_t st);
 void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st);

@@ -104,7 +104,127 @@ __global__ __launch_bounds__(256) void copy_kernel(const double2* __restrict__ s
     dst[i] = src[i];
 }
 
+__global__ __launch_bounds__(256) void fix_diag_kernel(double* A, int64_t lda, int n, int nvalid,
+                                                      double add) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double* p = A + (int64_t)i * lda + i;
+  *p = (i < nvalid) ? *p + add : 1.0;
+}
+
+__global__ __launch_bounds__(256) void unpermute_panel_kernel(const double* __restrict__ G,
+                                                             double* __restrict__ Pglob, int64_t ldp,
+                                                             int nb, int P, int p, int64_t maxcnt) {
+  // blockIdx.y = trailing block b (global block g = p+1+b), blockIdx.x strides rows of the block
+  const int g = p + 1 + blockIdx.y;
+  const int rr = g % P;
+  const int lb0 = (p >= rr) ? (p - rr) / P + 1 : 0;
+  const int64_t src_row0 = (int64_t)rr * maxcnt + (int64_t)(g / P - lb0) * nb;
+  const int64_t dst_row0 = (int64_t)blockIdx.y * nb;
+  const int c2 = nb / 2;  // double2 per row
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)nb * c2;
+       e += (int64_t)gridDim.x * 256) {
+    const int64_t row = e / c2;
+    const int col = (int)(e - row * c2) * 2;
+    *reinterpret_cast<double2*>(Pglob + (dst_row0 + row) * ldp + col) =
+        *reinterpret_cast<const double2*>(G + (src_row0 + row) * ldp + col);
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_rhs_local_kernel(const double* __restrict__ y, int64_t n,
+                                                            int k, double* __restrict__ YTloc,
+                                                            int64_t ldy, int nb, int nlb, int P,
+                                                            int rank) {
+  const int r = blockIdx.y;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < (int64_t)nlb * nb;
+       j += (int64_t)gridDim.x * 256) {
+    const int64_t lb = j / nb;
+    const int64_t gi = (lb * P + rank) * nb + (j - lb * nb);
+    YTloc[(int64_t)r * ldy + j] = (r < k && gi < n) ? y[gi * k + r] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_local_kernel(const double* __restrict__ Loc, int64_t ldl,
+                                                           double* __restrict__ Full, int64_t ldf,
+                                                           int nb, int nlb, int P, int rank) {
+  const int r = blockIdx.y;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < (int64_t)nlb * nb;
+       j += (int64_t)gridDim.x * 256) {
+    const int64_t lb = j / nb;
+    const int64_t gi = (lb * P + rank) * nb + (j - lb * nb);
+    Full[(int64_t)r * ldf + gi] = Loc[(int64_t)r * ldl + j];
+  }
+}
+
+__global__ __launch_bounds__(256) void add_block_kernel(double* __restrict__ dst, int64_t ldd,
+                                                       const double* __restrict__ src, int64_t lds,
+                                                       int rows, int cols, double sign) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)rows * cols;
+       e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / cols;
+    const int64_t c = e - r * cols;
+    dst[r * ldd + c] += sign * src[r * lds + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void add_scalar_kernel(double* p, int64_t count, double v) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    p[i] += v;
+}
+
+__global__ __launch_bounds__(256) void logdet_acc_kernel(const double* __restrict__ A, int64_t lda,
+                                                        int n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += log(A[i * lda + i]);
+  const double t = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] += 2.0 * t;
+}
+
 }  // namespace
+
+void launch_fix_diag(double* A, int64_t lda, int n, int nvalid, double add, hipStream_t st) {
+  hipLaunchKernelGGL(fix_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, lda, n, nvalid, add);
+}
+
+void launch_unpermute_panel(const double* G, double* Pglob, int64_t ldp, int nb, int P, int p,
+                            int nblk, int64_t maxcnt, hipStream_t st) {
+  const int ntb = nblk - p - 1;
+  if (ntb <= 0) return;
+  hipLaunchKernelGGL(unpermute_panel_kernel, dim3(64, (unsigned)ntb), dim3(256), 0, st, G, Pglob, ldp, nb, P, p, maxcnt);
+}
+
+void launch_pack_rhs_local(const double* y, int64_t n, int k, double* YTloc, int64_t ldy, int nb,
+                           int nlb, int P, int rank, int R, hipStream_t st) {
+  if (nlb <= 0) return;
+  const int64_t bx = ((int64_t)nlb * nb + 255) / 256;
+  hipLaunchKernelGGL(pack_rhs_local_kernel, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, y, n, k, YTloc, ldy, nb, nlb, P, rank);
+}
+
+void launch_scatter_local(const double* Loc, int64_t ldl, double* Full, int64_t ldf, int nb, int nlb,
+                          int P, int rank, int R, hipStream_t st) {
+  if (nlb <= 0) return;
+  const int64_t bx = ((int64_t)nlb * nb + 255) / 256;
+  hipLaunchKernelGGL(scatter_local_kernel, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, Loc, ldl, Full, ldf, nb, nlb, P, rank);
+}
+
+void launch_add_block(double* dst, int64_t ldd, const double* src, int64_t lds, int rows, int cols,
+                      double sign, hipStream_t st) {
+  const int64_t total = (int64_t)rows * cols;
+  if (total <= 0) return;
+  const int64_t bx = (total + 255) / 256;
+  hipLaunchKernelGGL(add_block_kernel, dim3((unsigned)(bx > 2048 ? 2048 : bx)), dim3(256), 0, st, dst, ldd, src, lds, rows, cols, sign);
+}
+
+void launch_add_scalar(double* p, int64_t count, double v, hipStream_t st) {
+  if (count <= 0) return;
+  const int64_t bx = (count + 255) / 256;
+  hipLaunchKernelGGL(add_scalar_kernel, dim3((unsigned)(bx > 1024 ? 1024 : bx)), dim3(256), 0, st, p, count, v);
+}
+
+void launch_logdet_acc(const double* A, int64_t lda, int n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(logdet_acc_kernel, dim3(1), dim3(256), 0, st, A, lda, n, out);
+}
 
 void launch_fill(double* p, int64_t count, double v, hipStream_t st) {
   if (count <= 0) return;

@@ -1,0 +1,120 @@
+"""Communicator bootstrap for the row-block shard.
+
+One process per GPU.  ``torch.distributed`` is only the control plane here: it ships the
+128-byte RCCL unique id (NCCL backend) or carries the host collectives themselves (gloo
+backend — used by the tests that run several ranks on ONE GPU, where RCCL refuses
+duplicate devices).  The data path is libgpx.so calling RCCL on its own HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+OP_SUM, OP_MIN = 0, 1
+
+
+def _torch_rccl_path():
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec and spec.origin:
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def init_rccl(lib, handle, rank, world, group=None):
+    """Rank 0 draws the unique id, every rank joins: gpx_comm_unique_id / gpx_comm_init."""
+    import torch.distributed as dist
+    if "GPX_RCCL_PATH" not in os.environ:
+        p = _torch_rccl_path()          # same RCCL build torch itself runs on
+        if p:
+            os.environ["GPX_RCCL_PATH"] = p
+    uid = C.create_string_buffer(128)
+    if rank == 0:
+        rc = lib.gpx_comm_unique_id(uid)
+        if rc != 0:
+            raise _abi.GpxError(rc, lib.gpx_last_error(None).decode())
+    if world > 1:
+        box = [uid.raw if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = C.create_string_buffer(box[0], 128)
+    rc = lib.gpx_comm_init(handle, uid)
+    if rc != 0:
+        raise _abi.GpxError(rc, lib.gpx_last_error(handle).decode())
+
+
+class HostCollectives:
+    """gpx_host_comm implemented with torch.distributed on CPU tensors (gloo)."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.last_error = None
+        # keep the CFUNCTYPE objects alive as long as the handle may call them
+        self._fns = (_abi.BCAST_FN(self._bcast), _abi.ALLGATHER_FN(self._allgather),
+                     _abi.REDUCE_FN(self._reduce), _abi.ALLREDUCE_FN(self._allreduce))
+        self.vtable = _abi.GpxHostComm(None, *self._fns)
+
+    def _view(self, addr, nbytes, dtype=np.uint8):
+        buf = (C.c_uint8 * nbytes).from_address(addr)
+        return self.torch.from_numpy(np.frombuffer(buf, dtype=dtype))
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            self.last_error = e
+            return 1
+
+    def _bcast(self, ctx, buf, nbytes, root):
+        return self._guard(lambda: self.dist.broadcast(self._view(buf, nbytes), src=root, group=self.group))
+
+    def _allgather(self, ctx, send, recv, nbytes):
+        def run():
+            out = self._view(recv, nbytes * self.world)
+            self.dist.all_gather(list(out.chunk(self.world)), self._view(send, nbytes), group=self.group)
+        return self._guard(run)
+
+    def _op(self, op):
+        return self.dist.ReduceOp.MIN if op == OP_MIN else self.dist.ReduceOp.SUM
+
+    def _reduce(self, ctx, send, recv, count, root, op):
+        def run():
+            t = self._view(send, count * 8, np.float64).clone()
+            self.dist.reduce(t, dst=root, op=self._op(op), group=self.group)
+            if self.rank == root:
+                self._view(recv, count * 8, np.float64).copy_(t)
+        return self._guard(run)
+
+    def _allreduce(self, ctx, buf, count, op):
+        return self._guard(lambda: self.dist.all_reduce(self._view(buf, count * 8, np.float64),
+                                                        op=self._op(op), group=self.group))
+
+    def attach(self, lib, handle):
+        rc = lib.gpx_comm_init_host(handle, C.byref(self.vtable))
+        if rc != 0:
+            raise _abi.GpxError(rc, lib.gpx_last_error(handle).decode())
+
+
+# ---- block-cyclic bookkeeping (mirror of struct Shard in csrc/gpx_shard.inc) -------------------
+def owner(g, P):
+    return g % P
+
+
+def blocks_owned(rank, nblk, P):
+    """global block indices stored by `rank`, in local order"""
+    return list(range(rank, nblk, P))
+
+
+def lb0(p, rank, P):
+    """number of blocks owned by `rank` with global index <= p"""
+    return (p - rank) // P + 1 if p >= rank else 0

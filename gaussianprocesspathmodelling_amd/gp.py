@@ -39,10 +39,17 @@ class GP:
     block : Cholesky panel width nb (multiple of 128; 0 = library default 512)
     max_tries : jitter escalations (x10 each) before ``LinAlgError``
     profile : record per-launch timings of the Cholesky sub-phases
+    world, rank : row-block shard of ONE Gram matrix over ``world`` processes (one per GPU).
+        Every rank passes the same full X, y, Xs and receives the full mean / var.
+    comm : "rccl" (RCCL on the library's stream; unique id shipped by torch.distributed),
+        "host" (collectives on host buffers through torch.distributed, e.g. gloo), or
+        None = pick from the initialised torch.distributed backend when world > 1.
+        ``comm`` with world == 1 runs the sharded schedule on one rank (tests).
     """
 
     def __init__(self, kernel="rbf", lengthscale=1.0, variance=1.0, noise=1e-2, jitter=None,
-                 dtype="float64", device=None, block=0, max_tries=3, profile=False):
+                 dtype="float64", device=None, block=0, max_tries=3, profile=False,
+                 world=1, rank=0, comm=None, group=None):
         if kernel not in _abi.KERNEL_IDS:
             raise ValueError(f"unknown kernel {kernel!r}; expected one of {sorted(_abi.KERNEL_IDS)}")
         if dtype not in _abi.DTYPE_IDS:
@@ -64,8 +71,9 @@ class GP:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = int(device)
         self._lib = _abi.load()
+        self.world, self.rank = int(world), int(rank)
         cfg = _abi.GpxConfig(kernel=_abi.KERNEL_IDS[kernel], dtype=_abi.DTYPE_IDS[dtype],
-                             device=self.device, block=self.block, rank=0, world=1,
+                             device=self.device, block=self.block, rank=self.rank, world=self.world,
                              flags=_abi.FLAG_PROFILE if profile else 0, reserved=0)
         h = C.c_void_p()
         rc = self._lib.gpx_create(C.byref(h), C.byref(cfg))
@@ -76,6 +84,28 @@ class GP:
         self._alpha = None
         self.info_ = 0
         self.jitter_used_ = self.jitter
+        self._host_comm = None
+        if self.world > 1 or comm is not None:
+            self._init_comm(comm, group)
+
+    def _init_comm(self, comm, group):
+        from . import dist as gdist
+        if comm is None:
+            import torch.distributed as tdist
+            if not tdist.is_initialized():
+                raise RuntimeError("world > 1 needs torch.distributed.init_process_group() first")
+            comm = "rccl" if tdist.get_backend(group) == "nccl" else "host"
+        try:
+            if comm == "rccl":
+                gdist.init_rccl(self._lib, self._h, self.rank, self.world, group)
+            elif comm == "host":
+                self._host_comm = gdist.HostCollectives(group)
+                self._host_comm.attach(self._lib, self._h)
+            else:
+                raise ValueError(f"unknown comm {comm!r}")
+        except Exception:
+            self.close()
+            raise
 
     # -- plumbing ---------------------------------------------------------------------
     def _check(self, rc):

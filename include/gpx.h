@@ -102,9 +102,23 @@ int gpx_get_timings(gpx_handle* h, gpx_timings* out);
 /* ---- row-block sharding over RCCL ------------------------------ */
 /* One process per GPU.  Rank 0 calls gpx_comm_unique_id and ships the 128 bytes to
  * the other ranks by any means (the Python host uses torch.distributed); every rank
- * then calls gpx_comm_init on its handle (created with the same world, own rank). */
+ * then calls gpx_comm_init on its handle (created with the same world, own rank).  A
+ * handle that owns a communicator — even a 1-rank one — runs the sharded schedule. */
 int gpx_comm_unique_id(void* id128);
 int gpx_comm_init(gpx_handle* h, const void* id128);
+
+/* Portable transport for the same shard schedule: collectives on HOST buffers supplied
+ * by the caller (e.g. torch.distributed/gloo); the library stages device<->host around
+ * each call.  Used by the multi-process tests that share one GPU (RCCL refuses duplicate
+ * devices) and for fabrics without RCCL.  op: 0 = sum, 1 = min.  Return 0 on success. */
+typedef struct gpx_host_comm {
+  void* ctx;
+  int (*bcast)(void* ctx, void* buf, int64_t bytes, int32_t root);
+  int (*allgather)(void* ctx, const void* send, void* recv, int64_t bytes_per_rank);
+  int (*reduce)(void* ctx, const double* send, double* recv, int64_t count, int32_t root, int32_t op);
+  int (*allreduce)(void* ctx, double* buf, int64_t count, int32_t op);
+} gpx_host_comm;
+int gpx_comm_init_host(gpx_handle* h, const gpx_host_comm* vt);
 
 /* ---- kernel unit-test entry points (host buffers, fp64) ------------------------- */
 /* K (na,nb) = sf2 k(A,B) (+ diag_add on the diagonal when B == NULL, i.e. B = A). */

@@ -1,0 +1,157 @@
+"""NumPy restatement of the row-block-cyclic sharded schedule.  TEST INFRASTRUCTURE ONLY.
+
+Mirrors ``gaussianprocesspathmodelling_amd/csrc/gpx_shard.inc`` step for step (owner
+factors the diagonal block, broadcast, local panel solve, padded all-gather + un-permute,
+local trailing update; forward solve with a broadcast per panel, backward solve with a
+reduce per panel; K*, mean and variance partials + all-reduce) with NumPy/SciPy blocks and
+``torch.distributed`` (gloo) collectives, so the schedule's arithmetic can be checked
+against the single-process oracle on CPU with world_size > 1.  The reference has no
+distributed code at all; the algorithm is SURVEY.md §8(e).
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.linalg import cholesky, solve_triangular
+
+from oracle.gp_oracle import kernel_matrix
+
+
+class NumpyCollectives:
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def bcast(self, arr, root):
+        t = self.torch.from_numpy(arr)
+        self.dist.broadcast(t, src=root, group=self.group)
+        return arr
+
+    def allgather(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr))
+        outs = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t, group=self.group)
+        return [o.numpy() for o in outs]
+
+    def reduce_sum(self, arr, root):
+        t = self.torch.from_numpy(arr.copy())
+        self.dist.reduce(t, dst=root, group=self.group)
+        return t.numpy() if self.rank == root else None
+
+    def allreduce_sum(self, arr):
+        t = self.torch.from_numpy(arr)
+        self.dist.all_reduce(t, group=self.group)
+        return arr
+
+
+def _lb0(p, r, P):
+    return (p - r) // P + 1 if p >= r else 0
+
+
+def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb):
+    P, r = coll.world, coll.rank
+    N, M = len(X), len(Xs)
+    Npad = -(-N // nb) * nb
+    nblk = Npad // nb
+    own = list(range(r, nblk, P))
+    nloc = len(own) * nb
+    Xp = np.zeros((Npad, X.shape[1]))
+    Xp[:N] = X
+    # local rows of K (identity padding), columns 0..Npad
+    A = np.zeros((max(nloc, 1), Npad))
+    for lb, g in enumerate(own):
+        rows = slice(g * nb, (g + 1) * nb)
+        blk = kernel_matrix(Xp[rows], Xp, kernel, ls, sf2)
+        gi = np.arange(g * nb, (g + 1) * nb)
+        blk[gi >= N, :] = 0.0
+        blk[:, N:] = 0.0
+        blk[np.arange(nb), gi] += np.where(gi < N, sn2, 1.0)
+        A[lb * nb:(lb + 1) * nb] = blk
+    logdet = np.zeros(1)
+    for p in range(nblk):
+        o, root, lo = p * nb, p % P, (p // P) * nb
+        D = np.zeros((nb, nb))
+        if r == root:
+            D[:] = cholesky(A[lo:lo + nb, o:o + nb], lower=True)
+            A[lo:lo + nb, o:o + nb] = D
+            logdet += 2.0 * np.sum(np.log(np.diag(D)))
+        if p + 1 == nblk:
+            break
+        coll.bcast(D, root)
+        l0 = _lb0(p, r, P)
+        rows = nloc - l0 * nb
+        if rows > 0:
+            A[l0 * nb:nloc, o:o + nb] = solve_triangular(D, A[l0 * nb:nloc, o:o + nb].T, lower=True).T
+        maxcnt = max((len(range(rr, nblk, P)) - _lb0(p, rr, P)) * nb for rr in range(P))
+        send = np.zeros((maxcnt, nb))
+        send[:rows] = A[l0 * nb:nloc, o:o + nb]
+        parts = coll.allgather(send)
+        Pg = np.zeros(((nblk - p - 1) * nb, nb))
+        for b in range(nblk - p - 1):
+            g = p + 1 + b
+            rr = g % P
+            idx = g // P - _lb0(p, rr, P)
+            Pg[b * nb:(b + 1) * nb] = parts[rr][idx * nb:(idx + 1) * nb]
+        for lb in range(l0, len(own)):
+            g = own[lb]
+            cols = slice((p + 1) * nb, (g + 1) * nb)
+            A[lb * nb:(lb + 1) * nb, cols] -= A[lb * nb:(lb + 1) * nb, o:o + nb] @ Pg[:(g - p) * nb].T
+    coll.allreduce_sum(logdet)
+
+    def local(v):  # (Npad, k) -> local rows
+        return np.concatenate([v[g * nb:(g + 1) * nb] for g in own]) if own else np.zeros((0, v.shape[1]))
+
+    Yp = np.zeros((Npad, 1))
+    Yp[:N, 0] = y
+    z = local(Yp)
+    for p in range(nblk):                      # forward: broadcast the solved block
+        o, root, lo = p * nb, p % P, (p // P) * nb
+        S = np.zeros((nb, 1))
+        if r == root:
+            z[lo:lo + nb] = solve_triangular(A[lo:lo + nb, o:o + nb], z[lo:lo + nb], lower=True)
+            S[:] = z[lo:lo + nb]
+        if p + 1 == nblk:
+            break
+        coll.bcast(S, root)
+        l0 = _lb0(p, r, P)
+        if nloc - l0 * nb > 0:
+            z[l0 * nb:] -= A[l0 * nb:nloc, o:o + nb] @ S
+    cneg = np.zeros((Npad, 1))
+    for p in range(nblk - 1, -1, -1):          # backward: reduce the partial products
+        o, root, lo = p * nb, p % P, (p // P) * nb
+        if p + 1 < nblk:
+            red = coll.reduce_sum(cneg[o:o + nb], root)
+        if r == root:
+            if p + 1 < nblk:
+                z[lo:lo + nb] += red
+            z[lo:lo + nb] = solve_triangular(A[lo:lo + nb, o:o + nb], z[lo:lo + nb], lower=True, trans="T")
+            cneg[:o] -= A[lo:lo + nb, :o].T @ z[lo:lo + nb]
+    alpha_full = np.zeros((Npad, 1))
+    for lb, g in enumerate(own):
+        alpha_full[g * nb:(g + 1) * nb] = z[lb * nb:(lb + 1) * nb]
+    coll.allreduce_sum(alpha_full)
+
+    Ks = np.zeros((M, max(nloc, 0)))
+    for lb, g in enumerate(own):
+        blk = kernel_matrix(Xs, Xp[g * nb:(g + 1) * nb], kernel, ls, sf2)
+        blk[:, np.arange(g * nb, (g + 1) * nb) >= N] = 0.0
+        Ks[:, lb * nb:(lb + 1) * nb] = blk
+    mean = Ks @ z if nloc else np.zeros((M, 1))
+    coll.allreduce_sum(mean)
+    V = Ks.copy()
+    for p in range(nblk):
+        o, root, lo = p * nb, p % P, (p // P) * nb
+        S = np.zeros((M, nb))
+        if r == root:
+            V[:, lo:lo + nb] = solve_triangular(A[lo:lo + nb, o:o + nb], V[:, lo:lo + nb].T, lower=True).T
+            S[:] = V[:, lo:lo + nb]
+        if p + 1 == nblk:
+            break
+        coll.bcast(S, root)
+        l0 = _lb0(p, r, P)
+        if nloc - l0 * nb > 0:
+            V[:, l0 * nb:] -= S @ A[l0 * nb:nloc, o:o + nb].T
+    part = -np.einsum("ij,ij->i", V, V)
+    coll.allreduce_sum(part)
+    return mean[:, 0], sf2 + part, alpha_full[:N, 0], float(logdet[0])

@@ -1,0 +1,64 @@
+"""Worker process of the shard tests: `python shard_worker.py MODE OUT.npz` with
+RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment.
+  MODE = oracle   NumPy restatement of the schedule (CPU, gloo)
+  MODE = callbacks  the ctypes host-collective callbacks on numpy buffers (CPU, gloo)
+  MODE = gpu      the HIP path, ranks sharing one GPU, host transport over gloo
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    mode, out = sys.argv[1], sys.argv[2]
+    nb = int(os.environ.get("SHARD_NB", "128"))
+    N = int(os.environ.get("SHARD_N", "700"))
+    M = int(os.environ.get("SHARD_M", "90"))
+    kernel = os.environ.get("SHARD_KERNEL", "rbf")
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.gp_oracle import synthetic_problem
+    X, y, Xs = synthetic_problem(N, 3, M, seed=77)
+    ls, sf2, sn2 = (0.3, 0.2, 0.25), 1.5, 1e-2
+    res = {}
+    if mode == "oracle":
+        from oracle.dist_oracle import NumpyCollectives, sharded_fit_predict
+        mean, var, alpha, logdet = sharded_fit_predict(NumpyCollectives(), X, y, Xs, kernel, ls, sf2, sn2, nb)
+        res = dict(mean=mean, var=var, alpha=alpha, logdet=logdet)
+    elif mode == "callbacks":
+        from gaussianprocesspathmodelling_amd.dist import HostCollectives
+        hc = HostCollectives()
+        vt = hc.vtable
+        a = np.arange(6, dtype=np.float64) + 10 * rank
+        vt.bcast(None, a.ctypes.data, a.nbytes, 1)
+        g = np.zeros(6 * world)
+        s = np.arange(6, dtype=np.float64) + 100 * rank
+        vt.allgather(None, s.ctypes.data, g.ctypes.data, s.nbytes)
+        r_out = np.full(6, -1.0)
+        vt.reduce(None, s.ctypes.data, r_out.ctypes.data, 6, 0, 0)
+        ar = np.array([float(rank), 5.0 - rank])
+        vt.allreduce(None, ar.ctypes.data, 2, 1)       # min
+        ar2 = np.array([float(rank + 1)])
+        vt.allreduce(None, ar2.ctypes.data, 1, 0)      # sum
+        res = dict(bcast=a, allgather=g, reduce=r_out, armin=ar, arsum=ar2, err=str(hc.last_error))
+    elif mode == "gpu":
+        os.environ["GPX_NB_SHARD"] = str(nb)
+        from gaussianprocesspathmodelling_amd import GP
+        with GP(kernel, ls, sf2, sn2, jitter=0.0, device=0, world=world, rank=rank, comm="host") as gp:
+            gp.fit(X, y)
+            mean, var = gp.predict(Xs)
+            res = dict(mean=mean, var=var, alpha=gp.alpha_, logdet=gp.log_det_, info=gp.info_,
+                       comm_ms=gp.timings_["comm"])
+    np.savez(out + f".rank{rank}.npz", **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

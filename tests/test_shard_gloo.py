@@ -1,0 +1,43 @@
+"""CPU, world_size 2 and 3 over gloo: (i) the host-collective callbacks the library calls,
+(ii) the NumPy restatement of the sharded schedule against the single-process oracle,
+(iii) the block-cyclic bookkeeping."""
+import numpy as np
+import pytest
+
+from gaussianprocesspathmodelling_amd import dist as gdist
+from oracle.gp_oracle import OracleGP, synthetic_problem
+from shard_util import run_ranks
+
+
+def test_block_cyclic_bookkeeping():
+    for P in (1, 2, 3, 8):
+        for nblk in (1, 2, 5, 16, 17):
+            owned = [gdist.blocks_owned(r, nblk, P) for r in range(P)]
+            assert sorted(sum(owned, [])) == list(range(nblk))
+            for p in range(nblk):
+                for r in range(P):
+                    assert gdist.lb0(p, r, P) == sum(1 for g in owned[r] if g <= p)
+
+
+def test_host_collective_callbacks_world2(tmp_path):
+    res = run_ranks("callbacks", 2, tmp_path)
+    for rank, r in enumerate(res):
+        assert r["err"] == "None"
+        assert np.array_equal(r["bcast"], np.arange(6.0) + 10)           # root 1's data everywhere
+        assert np.array_equal(r["allgather"], np.concatenate([np.arange(6.0), np.arange(6.0) + 100]))
+        assert np.array_equal(r["armin"], [0.0, 4.0]) and r["arsum"][0] == 3.0
+    assert np.array_equal(res[0]["reduce"], 2 * np.arange(6.0) + 100)
+    assert np.array_equal(res[1]["reduce"], np.full(6, -1.0))            # non-root untouched
+
+
+@pytest.mark.parametrize("world,kernel", [(2, "rbf"), (3, "matern52")])
+def test_sharded_schedule_matches_oracle(tmp_path, world, kernel):
+    res = run_ranks("oracle", world, tmp_path, {"SHARD_KERNEL": kernel, "SHARD_NB": "128"})
+    X, y, Xs = synthetic_problem(700, 3, 90, seed=77)
+    ref = OracleGP(kernel, (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    for r in res:
+        assert np.max(np.abs(r["mean"] - mr)) <= 1e-9 * max(1.0, np.abs(mr).max())
+        assert np.max(np.abs(r["var"] - vr) / np.maximum(vr, 1e-6 * 1.5)) <= 1e-7
+        assert np.max(np.abs(r["alpha"] - ref.alpha_)) <= 1e-8 * np.abs(ref.alpha_).max()
+        assert abs(float(r["logdet"]) - ref.log_det_) <= 1e-10 * abs(ref.log_det_)
