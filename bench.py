@@ -9,10 +9,14 @@ kernel, mean, variance TRSM) on BASELINE.json configs[2] — N=65536, d=3, RBF, 
 M=4096 (M fixed by SURVEY.md §8) — with X, y, Xs already resident in HBM (torch CUDA
 tensors are only the containers; all arithmetic is libgpx.so).
 
-N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU, every
-rank runs its own replica of the workload (independent GPs — e.g. one per path
-cluster — need no data-path collective), value = points of all ranks / max-over-ranks
-time, ``"scaling": "weak"``.
+N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU.
+  --mode replicas (default): every rank runs its own replica of the workload (independent
+      GPs — e.g. one per path cluster — need no data-path collective; north_star shards
+      the Gram matrix only when N outgrows one GPU), value = points of all ranks /
+      max-over-ranks time, ``"scaling": "weak"``.
+  --mode shard: ONE Gram matrix in row-block-cyclic shards over the ranks, panel
+      broadcast / all-gather over RCCL, value = (N+M) / time,
+      ``"scaling": "strong"``.  ``--workload C4`` = N=262144, d=3, Matern-5/2 (needs 8 GPUs).
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline     — the dominant kernel (trailing SYRK of the blocked Cholesky, fp64 MFMA):
@@ -91,6 +95,8 @@ def main():
     ap.add_argument("--n", type=int, default=N_TRAIN, help="override N (debug only; invalidates the metric)")
     ap.add_argument("--m", type=int, default=M_TEST)
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas")
+    ap.add_argument("--workload", choices=["C3", "C4"], default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
@@ -115,9 +121,21 @@ def main():
     from gaussianprocesspathmodelling_amd import GP, _abi
 
     N, M = args.n, args.m
-    X, y, Xs = synthetic(N, DIM, M, 12345 + rank)      # every replica its own draw
+    kernel = KERNEL
+    if args.workload == "C4":
+        if args.n == N_TRAIN:
+            N = 262144
+        kernel = "matern52"
+        if args.mode != "shard" or world < 2:
+            raise SystemExit("--workload C4 (550 GB Gram matrix) needs --mode shard on several GPUs")
+    shard = args.mode == "shard" and world > 1
+    X, y, Xs = synthetic(N, DIM, M, 12345 + (0 if shard else rank))   # replicas: own draw each
     Xd, yd, Xsd = (torch.from_numpy(a).to(dev) for a in (X, y, Xs))
-    gp = GP(KERNEL, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True)
+    if shard:
+        gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True,
+                world=world, rank=rank, comm="rccl")
+    else:
+        gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -153,18 +171,22 @@ def main():
         syrk_tflops = acc["syrk_flops"] / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
         launches = int(acc["syrk_launches"])
         phases = {k_: round(acc[k_] / steps, 3) for k_ in
-                  ("h2d", "kbuild", "chol", "chol_diag", "chol_trsm", "chol_strip", "chol_syrk", "solve", "logdet",
+                  ("comm", "h2d", "kbuild", "chol", "chol_diag", "chol_trsm", "chol_strip", "chol_syrk", "solve", "logdet",
                    "fit_total", "kstar", "mean", "trsm", "var", "d2h", "predict_total")}
         kb_ms = acc["kbuild"] / steps
         out = {
-            "metric": "gp_fit_predict_points_per_sec", "value": world * (N + M) * steps / elapsed,
+            "metric": "gp_fit_predict_points_per_sec",
+            "value": (1 if shard else world) * (N + M) * steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C3: exact GP fit+predict, N={N} d={DIM} RBF fp64, M={M}, "
-                                   f"inputs resident in HBM", "N": N, "d": DIM, "M": M,
-                       "kernel": KERNEL, "block": args.block or 1024,
-                       "parallelism": "1 gpu" if world == 1 else f"{world} independent replicas"},
+            "config": {"workload": f"{args.workload}: exact GP fit+predict, N={N} d={DIM} {kernel} fp64, "
+                                   f"M={M}, inputs resident in HBM", "N": N, "d": DIM, "M": M,
+                       "kernel": kernel, "block": args.block or 1024,
+                       "parallelism": "1 gpu" if world == 1 else
+                       (f"row-block-cyclic shard over {world} gpus (RCCL)" if shard
+                        else f"{world} independent replicas")},
             "outputs_finite": ok,
             "phases_ms": phases,
             "roofline": {
@@ -180,6 +202,10 @@ def main():
         out["kbuild"]["frac"] = out["kbuild"]["achieved"] / PEAK_HBM_GBS
         chol_ms = acc["chol"] / steps
         out["cholesky_tflops"] = (N ** 3 / 3.0) / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
+        if shard:   # the sharded update has no per-launch flop bookkeeping: rate the whole factorisation
+            out["roofline"].update(kernel="blocked Cholesky, all ranks (gemm_nt_kernel<128> with block-cyclic mask)",
+                                   achieved=out["cholesky_tflops"], peak=PEAK_FP64_MFMA_TFLOPS * world,
+                                   frac=out["cholesky_tflops"] / (PEAK_FP64_MFMA_TFLOPS * world))
         if world == 1 and not args.no_microbench:
             import ctypes as C
             a, b = C.c_double(0), C.c_double(0)
