@@ -92,11 +92,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=N_TRAIN, help="override N (debug only; invalidates the metric)")
-    ap.add_argument("--m", type=int, default=M_TEST)
+    ap.add_argument("--ntrain", dest="n", type=int, default=N_TRAIN, help="override N (debug only; invalidates the metric)")
+    ap.add_argument("--mtest", dest="m", type=int, default=M_TEST)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas")
     ap.add_argument("--workload", choices=["C3", "C4"], default="C3")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal of the multi-rank code on one GPU (host collectives)")
+    ap.add_argument("--device", type=int, default=None, help="HIP device override (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
@@ -112,11 +115,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    if args.device is not None:
+        local = args.device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from gaussianprocesspathmodelling_amd import GP, _abi
 
@@ -133,14 +141,17 @@ def main():
     Xd, yd, Xsd = (torch.from_numpy(a).to(dev) for a in (X, y, Xs))
     if shard:
         gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True,
-                world=world, rank=rank, comm="rccl")
+                world=world, rank=rank, comm="rccl" if args.backend == "nccl" else "host")
     else:
         gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True)
 
     def sync():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local])
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
             torch.cuda.synchronize(dev)
 
     def step():
@@ -160,7 +171,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ok = bool(torch.isfinite(mean).all().item() and (var > 0).all().item())
@@ -185,7 +196,7 @@ def main():
                                    f"M={M}, inputs resident in HBM", "N": N, "d": DIM, "M": M,
                        "kernel": kernel, "block": args.block or 1024,
                        "parallelism": "1 gpu" if world == 1 else
-                       (f"row-block-cyclic shard over {world} gpus (RCCL)" if shard
+                       (f"row-block-cyclic shard over {world} gpus ({'RCCL' if args.backend == 'nccl' else 'host collectives, rehearsal'})" if shard
                         else f"{world} independent replicas")},
             "outputs_finite": ok,
             "phases_ms": phases,

@@ -166,27 +166,29 @@ void collect_phases(gpx_handle* h) {
 // touch disjoint columns of A.
 
 // diagonal block [o, o+nbp) on stream s
-void diag_enqueue(double* A, int64_t ld, int64_t o, int nbp, double* Winv, int* info,
-                  int64_t gidx0, hipStream_t s) {
+template <typename T>
+void diag_enqueue(T* A, int64_t ld, int64_t o, int nbp, T* Winv, int* info, int64_t gidx0,
+                  hipStream_t s) {
   for (int q = 0; q < nbp / KB; ++q) {
     const int64_t oq = o + (int64_t)q * KB;
-    double* Aqq = A + oq * ld + oq;
-    double* Wq = Winv + (oq / KB) * (KB * KB);
+    T* Aqq = A + oq * ld + oq;
+    T* Wq = Winv + (oq / KB) * (KB * KB);
     launch_potf2_64(Aqq, ld, Wq, gidx0 + oq, info, s);
     const int64_t rem = o + nbp - (oq + KB);
     if (rem > 0) {
-      double* panel = A + (oq + KB) * ld + oq;
-      launch_trsm_rlt(panel, ld, rem, Aqq, ld, Wq, KB, nullptr, 0, s);
-      launch_gemm_nt(64, A + (oq + KB) * ld + (oq + KB), ld, panel, ld, panel, ld, rem, rem, KB, 1,
+      T* panel = A + (oq + KB) * ld + oq;
+      launch_trsm_rlt<T>(panel, ld, rem, Aqq, ld, Wq, KB, nullptr, 0, s);
+      launch_gemm_nt<T>(64, A + (oq + KB) * ld + (oq + KB), ld, panel, ld, panel, ld, rem, rem, KB, 1,
                      0, s);
     }
   }
 }
 
-void chol_enqueue(gpx_handle* h, double* A, int64_t ld, int64_t n, int nb, double* Winv, double* P0,
-                  double* P1, int64_t ldp, int* info, int64_t gidx0, bool profile) {
+template <typename T>
+void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T* P0, T* P1,
+                  int64_t ldp, int* info, int64_t gidx0, bool profile) {
   hipStream_t s0 = h->st, s1 = h->st2;
-  double* Pbuf[2] = {P0, P1};
+  T* Pbuf[2] = {P0, P1};
   // prologue: panel 0 on the main stream
   {
     const int nb0 = (int)std::min<int64_t>(nb, n);
@@ -196,7 +198,7 @@ void chol_enqueue(gpx_handle* h, double* A, int64_t ld, int64_t n, int nb, doubl
     }
     if (n - nb0 > 0) {
       PhaseScope ps(h, &h->tm.chol_trsm, profile);
-      launch_trsm_rlt(A + (int64_t)nb0 * ld, ld, n - nb0, A, ld, Winv, nb0, Pbuf[0], ldp, s0);
+      launch_trsm_rlt<T>(A + (int64_t)nb0 * ld, ld, n - nb0, A, ld, Winv, nb0, Pbuf[0], ldp, s0);
     }
   }
   int step = 0;
@@ -205,14 +207,14 @@ void chol_enqueue(gpx_handle* h, double* A, int64_t ld, int64_t n, int nb, doubl
     const int64_t t0 = o + nbp;          // first trailing row/col
     const int64_t ntrail = n - t0;
     if (ntrail <= 0) break;
-    double* Pc = Pbuf[step & 1];         // panel of this step, rows [t0, n)
-    double* Pn = Pbuf[(step + 1) & 1];
+    T* Pc = Pbuf[step & 1];         // panel of this step, rows [t0, n)
+    T* Pn = Pbuf[(step + 1) & 1];
     const int nbn = (int)std::min<int64_t>(nb, ntrail);  // width of the next panel
     const int64_t nrest = ntrail - nbn;
     const int tile = (ntrail % 128 == 0 && nbn % 128 == 0) ? 128 : 64;
     {  // STRIP: rows [t0, n) x cols [t0, t0+nbn), tiles on/below the diagonal
       PhaseScope ps(h, &h->tm.chol_strip, profile);
-      launch_gemm_nt(tile, A + t0 * ld + t0, ld, Pc, ldp, Pc, ldp, ntrail, nbn, nbp, 2, 0, s0);
+      launch_gemm_nt<T>(tile, A + t0 * ld + t0, ld, Pc, ldp, Pc, ldp, ntrail, nbn, nbp, 2, 0, s0);
     }
     hipEvent_t e_strip = next_event(h), e_panel = next_event(h);
     (void)hipEventRecord(e_strip, s0);
@@ -224,14 +226,14 @@ void chol_enqueue(gpx_handle* h, double* A, int64_t ld, int64_t n, int nb, doubl
       }
       if (nrest > 0) {
         PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
-        launch_trsm_rlt(A + (t0 + nbn) * ld + t0, ld, nrest, A + t0 * ld + t0, ld,
+        launch_trsm_rlt<T>(A + (t0 + nbn) * ld + t0, ld, nrest, A + t0 * ld + t0, ld,
                         Winv + (t0 / KB) * (KB * KB), nbn, Pn, ldp, s1);
       }
     }
     (void)hipEventRecord(e_panel, s1);
     if (nrest > 0) {  // REST: lower triangle of the trailing matrix beyond the strip
       PhaseScope ps(h, &h->tm.chol_syrk, profile);
-      launch_gemm_nt(tile, A + (t0 + nbn) * ld + (t0 + nbn), ld, Pc + (int64_t)nbn * ldp, ldp,
+      launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + (t0 + nbn), ld, Pc + (int64_t)nbn * ldp, ldp,
                      Pc + (int64_t)nbn * ldp, ldp, nrest, nrest, nbp, 1, 0, s0);
       h->tm.syrk_flops += (double)nrest * (double)(nrest + 1) * (double)nbp;
       h->tm.syrk_launches += 1;
@@ -241,30 +243,32 @@ void chol_enqueue(gpx_handle* h, double* A, int64_t ld, int64_t n, int nb, doubl
 }
 
 // XT (rows x n, ld) <- XT * L^-T   (i.e. X <- L^-1 X for X = XT^T), block forward substitution
-void solve_fwd_enqueue(gpx_handle* h, double* XT, int64_t rows, const double* L, int64_t ld,
-                       int64_t n, int nb, const double* Winv) {
+template <typename T>
+void solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld, int64_t n, int nb,
+                       const T* Winv) {
   hipStream_t st = h->st;
   const int tile = (rows % 128 == 0) ? 128 : 64;
   for (int64_t o = 0; o < n; o += nb) {
     const int nbp = (int)std::min<int64_t>(nb, n - o);
-    launch_trsm_rlt(XT + o, ld, rows, L + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, nullptr,
+    launch_trsm_rlt<T>(XT + o, ld, rows, L + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, nullptr,
                     0, st);
     const int64_t ntrail = n - (o + nbp);
     if (ntrail > 0)
-      launch_gemm_nt((ntrail % 128 == 0) ? tile : 64, XT + o + nbp, ld, XT + o, ld,
+      launch_gemm_nt<T>((ntrail % 128 == 0) ? tile : 64, XT + o + nbp, ld, XT + o, ld,
                      L + (o + nbp) * ld + o, ld, rows, ntrail, nbp, 0, 0, st);
   }
 }
 
 // XT (rows x n, ld) <- XT * L^-1   (X <- L^-T X), block back substitution; rows multiple of 64
-void solve_bwd_enqueue(gpx_handle* h, double* XT, int64_t rows, const double* L, int64_t ld,
-                       int64_t n, int nb, const double* Winv) {
+template <typename T>
+void solve_bwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld, int64_t n, int nb,
+                       const T* Winv) {
   hipStream_t st = h->st;
   int64_t last = ((n - 1) / nb) * nb;
   for (int64_t o = last; o >= 0; o -= nb) {
     const int nbp = (int)std::min<int64_t>(nb, n - o);
-    launch_trsm_rln(XT + o, ld, rows, L + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, st);
-    if (o > 0) launch_gemm_nn(XT, ld, XT + o, ld, L + o * ld, ld, rows, o, nbp, st);
+    launch_trsm_rln<T>(XT + o, ld, rows, L + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, st);
+    if (o > 0) launch_gemm_nn<T>(XT, ld, XT + o, ld, L + o * ld, ld, rows, o, nbp, st);
   }
 }
 
@@ -288,6 +292,153 @@ int copy_out(gpx_handle* h, void* dst, const void* src, size_t bytes, int mem_ki
 
 #include "gpx_shard.inc"
 
+namespace {
+
+template <typename T>
+int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
+             const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter,
+             int32_t mem_kind, int64_t* info) {
+  const int64_t Npad = round_up(N, TILE);
+  const int64_t ld = Npad + LD_SKEW;
+  const int64_t ldp = h->nb + LD_SKEW;
+  h->N = N; h->Npad = Npad; h->ld = ld; h->ldp = ldp; h->d = d; h->k = k; h->n_ls = n_ls;
+  h->sf2 = sf2; h->sn2 = sn2; h->jitter = jitter;
+  const bool profile = (h->cfg.flags & GPX_FLAG_PROFILE) != 0;
+  gpx_timings& tm = h->tm;
+  tm.h2d = tm.kbuild = tm.chol = tm.solve = tm.logdet = tm.fit_total = 0;
+  tm.chol_diag = tm.chol_trsm = tm.chol_strip = tm.chol_syrk = tm.syrk_flops = tm.comm = 0;
+  tm.syrk_launches = 0;
+  tm.kbuild_bytes = (double)sizeof(T) * ((double)N * (double)(N + 1) / 2.0 + (double)N * d);
+
+  int rc;
+  if ((rc = ensure(h, h->X, (size_t)N * d * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->Y, (size_t)N * k * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->Xs, (size_t)Npad * d * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->ls, 32 * 8))) return rc;
+  if ((rc = ensure(h, h->K, (size_t)Npad * ld * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->Winv, (size_t)(Npad / KB) * KB * KB * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->P, (size_t)2 * Npad * ldp * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->YT, (size_t)RHS_ROWS * ld * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->scalars, 64))) return rc;
+  if ((rc = ensure(h, h->info, 64))) return rc;
+
+  T* dK = (T*)h->K.p;
+  T* dYT = (T*)h->YT.p;
+  int* dInfo = (int*)h->info.p;
+  {
+    PhaseScope total(h, &tm.fit_total);
+    {
+      PhaseScope ps(h, &tm.h2d);
+      if ((rc = copy_in(h, h->X.p, X, (size_t)N * d * sizeof(T), mem_kind))) return rc;
+      if ((rc = copy_in(h, h->Y.p, y, (size_t)N * k * sizeof(T), mem_kind))) return rc;
+      if ((rc = copy_in(h, h->ls.p, lengthscale, (size_t)n_ls * 8, GPX_MEM_HOST))) return rc;
+      const int init = INT_MAX;
+      HIPCHK(h, hipMemcpyAsync(dInfo, &init, sizeof(int), hipMemcpyHostToDevice, h->st));
+    }
+    {
+      PhaseScope ps(h, &tm.kbuild);
+      launch_scale_points<T>((const T*)h->X.p, N, Npad, d, (const double*)h->ls.p, n_ls,
+                          (T*)h->Xs.p, h->st);
+      launch_kbuild_sym<T>(h->cfg.kernel, (const T*)h->Xs.p, N, Npad, d, sf2, sn2 + jitter, dK, ld,
+                        h->st);
+    }
+    {
+      PhaseScope ps(h, &tm.chol);
+      chol_enqueue<T>(h, dK, ld, Npad, h->nb, (T*)h->Winv.p, (T*)h->P.p,
+                   (T*)h->P.p + Npad * ldp, ldp, dInfo, 0, profile);
+    }
+    {
+      PhaseScope ps(h, &tm.solve);
+      launch_pack_rhs<T>((const T*)h->Y.p, N, k, dYT, ld, Npad, RHS_ROWS, h->st);
+      solve_fwd_enqueue<T>(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const T*)h->Winv.p);
+      solve_bwd_enqueue<T>(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const T*)h->Winv.p);
+    }
+    {
+      PhaseScope ps(h, &tm.logdet);
+      launch_logdet<T>(dK, ld, Npad, (double*)h->scalars.p, h->st);
+    }
+  }
+  int hinfo = 0;
+  HIPCHK(h, hipMemcpyAsync(&hinfo, dInfo, sizeof(int), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipMemcpyAsync(&h->logdet, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  HIPCHK(h, hipGetLastError());
+  collect_phases(h);
+  *info = (hinfo == INT_MAX) ? 0 : (int64_t)hinfo;
+  h->fitted = (*info == 0);
+  return GPX_OK;
+}
+
+template <typename T>
+int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var, int32_t mem_kind) {
+  const int64_t N = h->N, Npad = h->Npad, ld = h->ld;
+  const int d = h->d, k = h->k;
+  const int64_t Mpad = round_up(M, TILE);
+  const int64_t ldm = Mpad + LD_SKEW;
+  gpx_timings& tm = h->tm;
+  tm.kstar = tm.mean = tm.trsm = tm.var = tm.d2h = tm.predict_total = 0;
+
+  int rc;
+  if ((rc = ensure(h, h->Q, (size_t)M * d * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->Qs, (size_t)Mpad * d * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->VT, (size_t)Mpad * ld * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->MT, (size_t)RHS_ROWS * ldm * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->meanout, (size_t)M * k * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->var, (size_t)Mpad * sizeof(T)))) return rc;
+  T* dVT = (T*)h->VT.p;
+  const T* dK = (const T*)h->K.p;
+  const T* dWinv = (const T*)h->Winv.p;
+  {
+    PhaseScope total(h, &tm.predict_total);
+    {
+      PhaseScope ps(h, &tm.kstar);
+      if ((rc = copy_in(h, h->Q.p, Xq, (size_t)M * d * sizeof(T), mem_kind))) return rc;
+      launch_scale_points<T>((const T*)h->Q.p, M, Mpad, d, (const double*)h->ls.p, h->n_ls,
+                          (T*)h->Qs.p, h->st);
+      launch_kbuild_cross<T>(h->cfg.kernel, (const T*)h->Qs.p, M, Mpad, (const T*)h->Xs.p, N,
+                          Npad, d, h->sf2, dVT, ld, h->st);
+    }
+    {
+      // mean^T (64 x Mpad) = alpha^T (64 x Npad) * K*^T
+      PhaseScope ps(h, &tm.mean);
+      launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->YT.p, ld, dVT, ld, RHS_ROWS, Mpad,
+                     Npad, 0, 1, h->st);
+      launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, k, 1.0, (T*)h->meanout.p, h->st);
+    }
+    if (var) {
+      {
+        PhaseScope ps(h, &tm.trsm);
+        solve_fwd_enqueue<T>(h, dVT, Mpad, dK, ld, Npad, h->nb_pred, dWinv);
+      }
+      {
+        PhaseScope ps(h, &tm.var);
+        launch_var_rows<T>(dVT, ld, M, Npad, h->sf2, (T*)h->var.p, h->st);
+      }
+    }
+    {
+      PhaseScope ps(h, &tm.d2h);
+      if ((rc = copy_out(h, mean, h->meanout.p, (size_t)M * k * sizeof(T), mem_kind))) return rc;
+      if (var && (rc = copy_out(h, var, h->var.p, (size_t)M * sizeof(T), mem_kind))) return rc;
+    }
+  }
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  HIPCHK(h, hipGetLastError());
+  collect_phases(h);
+  return GPX_OK;
+}
+
+template <typename T>
+int alpha_impl(gpx_handle* h, void* out) {
+  int rc;
+  if ((rc = ensure(h, h->meanout, (size_t)h->N * h->k * sizeof(T)))) return rc;
+  launch_unpack_rhs<T>((const T*)h->YT.p, h->ld, h->N, h->k, 1.0, (T*)h->meanout.p, h->st);
+  HIPCHK(h, hipMemcpyAsync(out, h->meanout.p, (size_t)h->N * h->k * sizeof(T), hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return GPX_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int gpx_abi_version(void) { return GPX_ABI_VERSION; }
@@ -310,8 +461,10 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
   *out = nullptr;
   if (cfg->kernel != GPX_KERNEL_RBF && cfg->kernel != GPX_KERNEL_MATERN52)
     return fail(nullptr, GPX_E_ARG, "gpx_create: unknown kernel id");
-  if (cfg->dtype != GPX_F64)
-    return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: only GPX_F64 is implemented");
+  if (cfg->dtype != GPX_F64 && cfg->dtype != GPX_F32)
+    return fail(nullptr, GPX_E_ARG, "gpx_create: unknown dtype id");
+  if (cfg->dtype == GPX_F32 && cfg->world > 1)
+    return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: the row-block shard is fp64 only");
   if (cfg->world < 1 || cfg->world > 64 || cfg->rank < 0 || cfg->rank >= cfg->world)
     return fail(nullptr, GPX_E_ARG, "gpx_create: need 1 <= world <= 64 and 0 <= rank < world");
   const int nb = cfg->block == 0 ? 1024 : cfg->block;
@@ -380,75 +533,9 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
   if (h->cfg.world > 1 || h->comm)  // a 1-rank communicator also takes the sharded schedule
     return shard_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
 
-  const int64_t Npad = round_up(N, TILE);
-  const int64_t ld = Npad + LD_SKEW;
-  const int64_t ldp = h->nb + LD_SKEW;
-  h->N = N; h->Npad = Npad; h->ld = ld; h->ldp = ldp; h->d = d; h->k = k; h->n_ls = n_ls;
-  h->sf2 = sf2; h->sn2 = sn2; h->jitter = jitter;
-  const bool profile = (h->cfg.flags & GPX_FLAG_PROFILE) != 0;
-  gpx_timings& tm = h->tm;
-  tm.h2d = tm.kbuild = tm.chol = tm.solve = tm.logdet = tm.fit_total = 0;
-  tm.chol_diag = tm.chol_trsm = tm.chol_strip = tm.chol_syrk = tm.syrk_flops = tm.comm = 0;
-  tm.syrk_launches = 0;
-  tm.kbuild_bytes = 8.0 * ((double)N * (double)(N + 1) / 2.0 + (double)N * d);
-
-  int rc;
-  if ((rc = ensure(h, h->X, (size_t)N * d * 8))) return rc;
-  if ((rc = ensure(h, h->Y, (size_t)N * k * 8))) return rc;
-  if ((rc = ensure(h, h->Xs, (size_t)Npad * d * 8))) return rc;
-  if ((rc = ensure(h, h->ls, 32 * 8))) return rc;
-  if ((rc = ensure(h, h->K, (size_t)Npad * ld * 8))) return rc;
-  if ((rc = ensure(h, h->Winv, (size_t)(Npad / KB) * KB * KB * 8))) return rc;
-  if ((rc = ensure(h, h->P, (size_t)2 * Npad * ldp * 8))) return rc;
-  if ((rc = ensure(h, h->YT, (size_t)RHS_ROWS * ld * 8))) return rc;
-  if ((rc = ensure(h, h->scalars, 64))) return rc;
-  if ((rc = ensure(h, h->info, 64))) return rc;
-
-  double* dK = (double*)h->K.p;
-  double* dYT = (double*)h->YT.p;
-  int* dInfo = (int*)h->info.p;
-  {
-    PhaseScope total(h, &tm.fit_total);
-    {
-      PhaseScope ps(h, &tm.h2d);
-      if ((rc = copy_in(h, h->X.p, X, (size_t)N * d * 8, mem_kind))) return rc;
-      if ((rc = copy_in(h, h->Y.p, y, (size_t)N * k * 8, mem_kind))) return rc;
-      if ((rc = copy_in(h, h->ls.p, lengthscale, (size_t)n_ls * 8, GPX_MEM_HOST))) return rc;
-      const int init = INT_MAX;
-      HIPCHK(h, hipMemcpyAsync(dInfo, &init, sizeof(int), hipMemcpyHostToDevice, h->st));
-    }
-    {
-      PhaseScope ps(h, &tm.kbuild);
-      launch_scale_points((const double*)h->X.p, N, Npad, d, (const double*)h->ls.p, n_ls,
-                          (double*)h->Xs.p, h->st);
-      launch_kbuild_sym(h->cfg.kernel, (const double*)h->Xs.p, N, Npad, d, sf2, sn2 + jitter, dK, ld,
-                        h->st);
-    }
-    {
-      PhaseScope ps(h, &tm.chol);
-      chol_enqueue(h, dK, ld, Npad, h->nb, (double*)h->Winv.p, (double*)h->P.p,
-                   (double*)h->P.p + Npad * ldp, ldp, dInfo, 0, profile);
-    }
-    {
-      PhaseScope ps(h, &tm.solve);
-      launch_pack_rhs((const double*)h->Y.p, N, k, dYT, ld, Npad, RHS_ROWS, h->st);
-      solve_fwd_enqueue(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const double*)h->Winv.p);
-      solve_bwd_enqueue(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const double*)h->Winv.p);
-    }
-    {
-      PhaseScope ps(h, &tm.logdet);
-      launch_logdet(dK, ld, Npad, (double*)h->scalars.p, h->st);
-    }
-  }
-  int hinfo = 0;
-  HIPCHK(h, hipMemcpyAsync(&hinfo, dInfo, sizeof(int), hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipMemcpyAsync(&h->logdet, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipStreamSynchronize(h->st));
-  HIPCHK(h, hipGetLastError());
-  collect_phases(h);
-  *info = (hinfo == INT_MAX) ? 0 : (int64_t)hinfo;
-  h->fitted = (*info == 0);
-  return GPX_OK;
+  if (h->cfg.dtype == GPX_F32)
+    return fit_impl<float>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
+  return fit_impl<double>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
 }
 
 int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var, int32_t mem_kind) {
@@ -460,72 +547,16 @@ int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var,
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->err.clear();
   if (h->cfg.world > 1 || h->comm) return shard_predict(h, Xq, M, mean, var, mem_kind);
-  const int64_t N = h->N, Npad = h->Npad, ld = h->ld;
-  const int d = h->d, k = h->k;
-  const int64_t Mpad = round_up(M, TILE);
-  const int64_t ldm = Mpad + LD_SKEW;
-  gpx_timings& tm = h->tm;
-  tm.kstar = tm.mean = tm.trsm = tm.var = tm.d2h = tm.predict_total = 0;
-
-  int rc;
-  if ((rc = ensure(h, h->Q, (size_t)M * d * 8))) return rc;
-  if ((rc = ensure(h, h->Qs, (size_t)Mpad * d * 8))) return rc;
-  if ((rc = ensure(h, h->VT, (size_t)Mpad * ld * 8))) return rc;
-  if ((rc = ensure(h, h->MT, (size_t)RHS_ROWS * ldm * 8))) return rc;
-  if ((rc = ensure(h, h->meanout, (size_t)M * k * 8))) return rc;
-  if ((rc = ensure(h, h->var, (size_t)Mpad * 8))) return rc;
-  double* dVT = (double*)h->VT.p;
-  const double* dK = (const double*)h->K.p;
-  const double* dWinv = (const double*)h->Winv.p;
-  {
-    PhaseScope total(h, &tm.predict_total);
-    {
-      PhaseScope ps(h, &tm.kstar);
-      if ((rc = copy_in(h, h->Q.p, Xq, (size_t)M * d * 8, mem_kind))) return rc;
-      launch_scale_points((const double*)h->Q.p, M, Mpad, d, (const double*)h->ls.p, h->n_ls,
-                          (double*)h->Qs.p, h->st);
-      launch_kbuild_cross(h->cfg.kernel, (const double*)h->Qs.p, M, Mpad, (const double*)h->Xs.p, N,
-                          Npad, d, h->sf2, dVT, ld, h->st);
-    }
-    {
-      // mean^T (64 x Mpad) = alpha^T (64 x Npad) * K*^T
-      PhaseScope ps(h, &tm.mean);
-      launch_gemm_nt(64, (double*)h->MT.p, ldm, (const double*)h->YT.p, ld, dVT, ld, RHS_ROWS, Mpad,
-                     Npad, 0, 1, h->st);
-      launch_unpack_rhs((const double*)h->MT.p, ldm, M, k, 1.0, (double*)h->meanout.p, h->st);
-    }
-    if (var) {
-      {
-        PhaseScope ps(h, &tm.trsm);
-        solve_fwd_enqueue(h, dVT, Mpad, dK, ld, Npad, h->nb_pred, dWinv);
-      }
-      {
-        PhaseScope ps(h, &tm.var);
-        launch_var_rows(dVT, ld, M, Npad, h->sf2, (double*)h->var.p, h->st);
-      }
-    }
-    {
-      PhaseScope ps(h, &tm.d2h);
-      if ((rc = copy_out(h, mean, h->meanout.p, (size_t)M * k * 8, mem_kind))) return rc;
-      if (var && (rc = copy_out(h, var, h->var.p, (size_t)M * 8, mem_kind))) return rc;
-    }
-  }
-  HIPCHK(h, hipStreamSynchronize(h->st));
-  HIPCHK(h, hipGetLastError());
-  collect_phases(h);
-  return GPX_OK;
+  if (h->cfg.dtype == GPX_F32) return predict_impl<float>(h, Xq, M, mean, var, mem_kind);
+  return predict_impl<double>(h, Xq, M, mean, var, mem_kind);
 }
 
 int gpx_get_alpha(gpx_handle* h, void* out) {
   if (!h) return GPX_E_ARG;
   if (!h->fitted || !out) return fail(h, GPX_E_ARG, "gpx_get_alpha: no fit or null output");
   HIPCHK(h, hipSetDevice(h->cfg.device));
-  int rc;
-  if ((rc = ensure(h, h->meanout, (size_t)h->N * h->k * 8))) return rc;
-  launch_unpack_rhs((const double*)h->YT.p, h->ld, h->N, h->k, 1.0, (double*)h->meanout.p, h->st);
-  HIPCHK(h, hipMemcpyAsync(out, h->meanout.p, (size_t)h->N * h->k * 8, hipMemcpyDeviceToHost, h->st));
-  HIPCHK(h, hipStreamSynchronize(h->st));
-  return GPX_OK;
+  if (h->cfg.dtype == GPX_F32) return alpha_impl<float>(h, out);
+  return alpha_impl<double>(h, out);
 }
 
 int gpx_logdet(gpx_handle* h, double* out) {
@@ -681,7 +712,7 @@ int gpx_trsm(double* X, int64_t m, const double* L, int64_t nb) {
   }
   for (int64_t q = 0; q < nb / 64; ++q)
     launch_potf2_64(dL2 + q * 4096, 64, dW + q * 4096, q * 64, dInfo, st);
-  launch_trsm_rlt(dX, ldx, m, dL, ldl, dW, (int)nb, nullptr, 0, st);
+  launch_trsm_rlt<double>(dX, ldx, m, dL, ldl, dW, (int)nb, nullptr, 0, st);
   TCHK(hipMemcpy2DAsync(X, (size_t)nb * 8, dX, (size_t)ldx * 8, (size_t)nb * 8, (size_t)m, hipMemcpyDeviceToHost, st));
   TCHK(hipStreamSynchronize(st));
   TCHK(hipGetLastError());
@@ -730,6 +761,25 @@ int gpx_mfma_probe(const double* A, const double* B, double* D) {
   TCHK(hipMemcpyAsync(d + 64, B, 64 * 8, hipMemcpyHostToDevice, st));
   launch_mfma_probe(d, d + 64, d + 128, st);
   TCHK(hipMemcpyAsync(D, d + 128, 256 * 8, hipMemcpyDeviceToHost, st));
+  TCHK(hipStreamSynchronize(st));
+  TCHK(hipGetLastError());
+done:
+  if (d) (void)hipFree(d);
+  return rc;
+}
+
+int gpx_mfma_probe_f32(const float* A, const float* B, float* D) {
+  if (!A || !B || !D) return GPX_E_ARG;
+  Scratch sc;
+  if (!sc.ok) return GPX_E_HIP;
+  hipStream_t st = sc.h.st;
+  float* d = nullptr;
+  int rc = GPX_OK;
+  TCHK(hipMalloc(&d, (64 + 64 + 256) * 4));
+  TCHK(hipMemcpyAsync(d, A, 64 * 4, hipMemcpyHostToDevice, st));
+  TCHK(hipMemcpyAsync(d + 64, B, 64 * 4, hipMemcpyHostToDevice, st));
+  launch_mfma_probe_f32(d, d + 64, d + 128, st);
+  TCHK(hipMemcpyAsync(D, d + 128, 256 * 4, hipMemcpyDeviceToHost, st));
   TCHK(hipStreamSynchronize(st));
   TCHK(hipGetLastError());
 done:

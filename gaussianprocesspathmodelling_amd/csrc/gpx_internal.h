@@ -1,5 +1,6 @@
 // gpx_internal.h — launcher prototypes shared by the kernel TUs and the C-ABI TU.
-// All launchers enqueue on `st` and never synchronise.
+// All launchers enqueue on `st` and never synchronise.  Every launcher is a template on
+// the element type T, explicitly instantiated for double and float in its .hip file.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,67 +9,79 @@ namespace gpx {
 
 constexpr int KB = 64;      // innermost Cholesky block (one-workgroup POTF2 + inverse)
 constexpr int TILE = 128;   // trailing-update tile; every padded dimension is a multiple
-constexpr int LD_SKEW = 16; // leading-dimension skew (doubles) against power-of-two strides
+constexpr int LD_SKEW = 16; // leading-dimension skew (elements) against power-of-two strides
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // ---- kernel-matrix build (gpx_kbuild.hip) ---------------------------------------
 // Xs = X / lengthscale (per-dimension), rows >= n zero-filled up to npad.
-void launch_scale_points(const double* X, int64_t n, int64_t npad, int d, const double* ls,
-                         int n_ls, double* Xs, hipStream_t st);
-// Lower tiles (64x64) of K[npad, npad] (ld): sf2*k(xi,xj), + diag_add on the diagonal;
-// padded rows/cols (>= n) become identity rows.  rows [row0, row0+nrows) only.
-void launch_kbuild_sym(int kernel, const double* Xs, int64_t n, int64_t npad, int d, double sf2,
-                       double diag_add, double* K, int64_t ld, hipStream_t st);
-// Rectangular K*[mpad, npad] (ld) = sf2*k(As_i, Bs_j); rows >= m or cols >= n are zero.
-void launch_kbuild_cross(int kernel, const double* As, int64_t m, int64_t mpad, const double* Bs,
-                         int64_t n, int64_t npad, int d, double sf2, double* K, int64_t ld,
+template <typename T>
+void launch_scale_points(const T* X, int64_t n, int64_t npad, int d, const double* ls, int n_ls, T* Xs,
                          hipStream_t st);
+// Lower tiles (64x64) of K[npad, npad] (ld): sf2*k(xi,xj), + diag_add on the diagonal;
+// padded rows/cols (>= n) become identity rows.
+template <typename T>
+void launch_kbuild_sym(int kernel, const T* Xs, int64_t n, int64_t npad, int d, double sf2,
+                       double diag_add, T* K, int64_t ld, hipStream_t st);
+// Rectangular K*[mpad, npad] (ld) = sf2*k(As_i, Bs_j); rows >= m or cols >= n are zero.
+template <typename T>
+void launch_kbuild_cross(int kernel, const T* As, int64_t m, int64_t mpad, const T* Bs, int64_t n,
+                         int64_t npad, int d, double sf2, T* K, int64_t ld, hipStream_t st);
 
 // ---- dense blocks (gpx_blas.hip) ---------------------------------------------------
 // In-place Cholesky of one 64x64 diagonal block (lower) + its inverse Winv (64x64,
 // row-major, upper part zero).  gidx0 = global index of the block's first row (info).
-void launch_potf2_64(double* A, int64_t lda, double* Winv, int64_t gidx0, int* info,
-                     hipStream_t st);
+template <typename T>
+void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st);
 // X (rows x nb, ldx) <- X * L^-T; L (nb x nb, ldl) lower, Winv = nb/64 inverse diag
 // blocks.  rows, nb multiples of 64.  If P != null the result is also written to the
 // compact panel P (rows x nb, ldp).
-void launch_trsm_rlt(double* X, int64_t ldx, int64_t rows, const double* L, int64_t ldl,
-                     const double* Winv, int nb, double* P, int64_t ldp, hipStream_t st);
+template <typename T>
+void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, const T* Winv, int nb,
+                     T* P, int64_t ldp, hipStream_t st);
 // X (rows x nb, ldx) <- X * L^-1 (right, lower, no-transpose; descending blocks).
-void launch_trsm_rln(double* X, int64_t ldx, int64_t rows, const double* L, int64_t ldl,
-                     const double* Winv, int nb, hipStream_t st);
+template <typename T>
+void launch_trsm_rln(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, const T* Winv, int nb,
+                     hipStream_t st);
 // C (m x n, ldc) op= A (m x k, lda) * B (n x k, ldb)^T.
 //   mode 0: C -= A B^T      mode 1: C = A B^T
 //   lower 0: every tile;  1: lower triangle (m == n), triangular super-tile order;
 //         2: rectangle masked to tile_col <= tile_row (look-ahead strip).
-//   tile = 128 (m,n multiples of 128) or 64 (multiples of 64); k multiple of 16.
-void launch_gemm_nt(int tile, double* C, int64_t ldc, const double* A, int64_t lda,
-                    const double* B, int64_t ldb, int64_t m, int64_t n, int64_t k, int lower,
-                    int mode, hipStream_t st);
+//   tile = 128 (m,n multiples of 128) or 64 (multiples of 64); k multiple of 64.
+template <typename T>
+void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
+                    int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st);
 // Sharded trailing update: C (m local rows x n, 128-tiles) -= A B^T restricted to tiles with
 //   tile_col <= ((tile_row / tpb) * P + c) * tpb + tile_row % tpb   (block-cyclic rows).
-void launch_gemm_nt_bc(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                       int64_t ldb, int64_t m, int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c,
-                       hipStream_t st);
+template <typename T>
+void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
+                       int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c, hipStream_t st);
 // C (m x n, ldc) -= A (m x k, lda) * B (k x n, ldb); 64x64 tiles.
-void launch_gemm_nn(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                    int64_t ldb, int64_t m, int64_t n, int64_t k, hipStream_t st);
+template <typename T>
+void launch_gemm_nn(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
+                    int64_t n, int64_t k, hipStream_t st);
 
 // ---- small helpers (gpx_misc.hip) ------------------------------------------------------
 // YT (R x npad, ld) <- transpose of y (n x k) into rows [0,k), everything else zero.
-void launch_pack_rhs(const double* y, int64_t n, int k, double* YT, int64_t ld, int64_t npad,
-                     int R, hipStream_t st);
+template <typename T>
+void launch_pack_rhs(const T* y, int64_t n, int k, T* YT, int64_t ld, int64_t npad, int R,
+                     hipStream_t st);
 // out (n x k) <- rows [0,k) of YT (R x *, ld), scaled by `scale`.
-void launch_unpack_rhs(const double* YT, int64_t ld, int64_t n, int k, double scale, double* out,
-                       hipStream_t st);
-// var[i] = sf2 - sum_j VT[i, j]^2, i < m.
-void launch_var_rows(const double* VT, int64_t ld, int64_t m, int64_t ncols, double sf2,
-                     double* var, hipStream_t st);
-// out[0] = 2 * sum_{i<n} log(A[i, i]).
-void launch_logdet(const double* A, int64_t lda, int64_t n, double* out, hipStream_t st);
-void launch_fill(double* p, int64_t count, double v, hipStream_t st);
-// ---- row-block-cyclic shard helpers (gpx_misc.hip) ----------------------------------------
+template <typename T>
+void launch_unpack_rhs(const T* YT, int64_t ld, int64_t n, int k, double scale, T* out, hipStream_t st);
+// var[i] = sf2 - sum_j VT[i, j]^2, i < m  (accumulated in fp64).
+template <typename T>
+void launch_var_rows(const T* VT, int64_t ld, int64_t m, int64_t ncols, double sf2, T* var,
+                     hipStream_t st);
+// out[0] = 2 * sum_{i<n} log(A[i, i])  (fp64 accumulation and result).
+template <typename T>
+void launch_logdet(const T* A, int64_t lda, int64_t n, double* out, hipStream_t st);
+void launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st);
+void launch_mfma_probe_f32(const float* A, const float* B, float* D, hipStream_t st);
+void launch_mfma_loop(double* sink, int iters, int blocks, hipStream_t st);
+void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st);
+
+// ---- row-block-cyclic shard helpers (gpx_misc.hip, fp64) ----------------------------------
 // A[i][i] = i < nvalid ? A[i][i] + add : 1   for i < n (diagonal of one local row block)
 void launch_fix_diag(double* A, int64_t lda, int n, int nvalid, double add, hipStream_t st);
 // Gathered panel G [P][maxcnt][ldp] (rank-major, each rank's trailing rows in local order)
@@ -87,8 +100,5 @@ void launch_add_block(double* dst, int64_t ldd, const double* src, int64_t lds, 
 void launch_add_scalar(double* p, int64_t count, double v, hipStream_t st);
 // out[0] += 2 * sum_i log(A[i][i]), i < n (one diagonal block)
 void launch_logdet_acc(const double* A, int64_t lda, int n, double* out, hipStream_t st);
-void launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st);
-void launch_mfma_loop(double* sink, int iters, int blocks, hipStream_t st);
-void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st);
 
 }  // namespace gpx

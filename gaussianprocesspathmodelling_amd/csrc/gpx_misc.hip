@@ -9,28 +9,23 @@ namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void fill_kernel(double* p, int64_t count, double v) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
-    p[i] = v;
-}
-
 // YT[r][i] = (r < k && i < n) ? y[i*k + r] : 0
-__global__ __launch_bounds__(256) void pack_rhs_kernel(const double* __restrict__ y, int64_t n, int k,
-                                                      double* __restrict__ YT, int64_t ld,
-                                                      int64_t npad) {
+template <typename T>
+__global__ __launch_bounds__(256) void pack_rhs_kernel(const T* __restrict__ y, int64_t n, int k,
+                                                      T* __restrict__ YT, int64_t ld, int64_t npad) {
   const int r = blockIdx.y;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npad; i += (int64_t)gridDim.x * 256)
-    YT[(int64_t)r * ld + i] = (r < k && i < n) ? y[i * k + r] : 0.0;
+    YT[(int64_t)r * ld + i] = (r < k && i < n) ? y[i * k + r] : (T)0;
 }
 
-__global__ __launch_bounds__(256) void unpack_rhs_kernel(const double* __restrict__ YT, int64_t ld,
-                                                        int64_t n, int k, double scale,
-                                                        double* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_rhs_kernel(const T* __restrict__ YT, int64_t ld, int64_t n,
+                                                        int k, double scale, T* __restrict__ out) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n * k) return;
   const int64_t i = idx / k;
   const int r = (int)(idx - i * k);
-  out[idx] = scale * YT[(int64_t)r * ld + i];
+  out[idx] = (T)(scale * (double)YT[(int64_t)r * ld + i]);
 }
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -44,27 +39,29 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return s;
 }
 
-// one workgroup per row: var[i] = sf2 - sum_j VT[i][j]^2  (fixed summation order)
-__global__ __launch_bounds__(256) void var_rows_kernel(const double* __restrict__ VT, int64_t ld,
-                                                      int64_t ncols, double sf2,
-                                                      double* __restrict__ var) {
+// one workgroup per row: var[i] = sf2 - sum_j VT[i][j]^2  (fp64 accumulation, fixed order)
+template <typename T>
+__global__ __launch_bounds__(256) void var_rows_kernel(const T* __restrict__ VT, int64_t ld,
+                                                      int64_t ncols, double sf2, T* __restrict__ var) {
+  typedef T pair_t __attribute__((ext_vector_type(2)));
   __shared__ double red[4];
-  const double* row = VT + (int64_t)blockIdx.x * ld;
+  const T* row = VT + (int64_t)blockIdx.x * ld;
   double s0 = 0.0, s1 = 0.0;
   for (int64_t j = (int64_t)threadIdx.x * 2; j < ncols; j += 512) {
-    const double2 v = *reinterpret_cast<const double2*>(row + j);
-    s0 += v.x * v.x;
-    s1 += v.y * v.y;
+    const pair_t v = *reinterpret_cast<const pair_t*>(row + j);
+    s0 += (double)v.x * (double)v.x;
+    s1 += (double)v.y * (double)v.y;
   }
   const double s = block_sum(s0 + s1, red);
-  if (threadIdx.x == 0) var[blockIdx.x] = sf2 - s;
+  if (threadIdx.x == 0) var[blockIdx.x] = (T)(sf2 - s);
 }
 
-__global__ __launch_bounds__(256) void logdet_kernel(const double* __restrict__ A, int64_t lda,
-                                                    int64_t n, double* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(256) void logdet_kernel(const T* __restrict__ A, int64_t lda, int64_t n,
+                                                    double* __restrict__ out) {
   __shared__ double red[4];
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s += log(A[i * lda + i]);
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += log((double)A[i * lda + i]);
   const double t = block_sum(s, red);
   if (threadIdx.x == 0) out[0] = 2.0 * t;
 }
@@ -78,6 +75,18 @@ __global__ __launch_bounds__(64) void mfma_probe_kernel(const double* A, const d
   c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 #pragma unroll
   for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = c[r];
+}
+
+// same probe for v_mfma_f32_16x16x4_f32: D reg r of lane l = D[4(l>>4) + r][l&15]
+__global__ __launch_bounds__(64) void mfma_probe_f32_kernel(const float* A, const float* B, float* D) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int l = threadIdx.x;
+  const float a = A[(l & 15) * 4 + (l >> 4)];
+  const float b = B[(l >> 4) * 16 + (l & 15)];
+  v4f c = {0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) D[(4 * (l >> 4) + r) * 16 + (l & 15)] = c[r];
 }
 
 // register-resident fp64 MFMA loop: 16 independent accumulators per wave
@@ -226,33 +235,40 @@ void launch_logdet_acc(const double* A, int64_t lda, int n, double* out, hipStre
   hipLaunchKernelGGL(logdet_acc_kernel, dim3(1), dim3(256), 0, st, A, lda, n, out);
 }
 
-void launch_fill(double* p, int64_t count, double v, hipStream_t st) {
-  if (count <= 0) return;
-  const int64_t blocks = (count + 255) / 256;
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, p, count, v);
-}
-
-void launch_pack_rhs(const double* y, int64_t n, int k, double* YT, int64_t ld, int64_t npad, int R,
-                     hipStream_t st) {
+template <typename T>
+void launch_pack_rhs(const T* y, int64_t n, int k, T* YT, int64_t ld, int64_t npad, int R, hipStream_t st) {
   const int64_t bx = (npad + 255) / 256;
-  hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, y, n, k, YT, ld, npad);
+  hipLaunchKernelGGL(pack_rhs_kernel<T>, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, y, n, k, YT, ld, npad);
 }
 
-void launch_unpack_rhs(const double* YT, int64_t ld, int64_t n, int k, double scale, double* out,
-                       hipStream_t st) {
+template <typename T>
+void launch_unpack_rhs(const T* YT, int64_t ld, int64_t n, int k, double scale, T* out, hipStream_t st) {
   const int64_t total = n * k;
   if (total <= 0) return;
-  hipLaunchKernelGGL(unpack_rhs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, YT, ld, n, k, scale, out);
+  hipLaunchKernelGGL(unpack_rhs_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, YT, ld, n, k, scale, out);
 }
 
-void launch_var_rows(const double* VT, int64_t ld, int64_t m, int64_t ncols, double sf2, double* var,
-                     hipStream_t st) {
+template <typename T>
+void launch_var_rows(const T* VT, int64_t ld, int64_t m, int64_t ncols, double sf2, T* var, hipStream_t st) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(var_rows_kernel, dim3((unsigned)m), dim3(256), 0, st, VT, ld, ncols, sf2, var);
+  hipLaunchKernelGGL(var_rows_kernel<T>, dim3((unsigned)m), dim3(256), 0, st, VT, ld, ncols, sf2, var);
 }
 
-void launch_logdet(const double* A, int64_t lda, int64_t n, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(256), 0, st, A, lda, n, out);
+template <typename T>
+void launch_logdet(const T* A, int64_t lda, int64_t n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, n, out);
+}
+
+#define GPX_INSTANTIATE_MISC(T)                                                                    \
+  template void launch_pack_rhs<T>(const T*, int64_t, int, T*, int64_t, int64_t, int, hipStream_t); \
+  template void launch_unpack_rhs<T>(const T*, int64_t, int64_t, int, double, T*, hipStream_t);     \
+  template void launch_var_rows<T>(const T*, int64_t, int64_t, int64_t, double, T*, hipStream_t);   \
+  template void launch_logdet<T>(const T*, int64_t, int64_t, double*, hipStream_t);
+GPX_INSTANTIATE_MISC(double)
+GPX_INSTANTIATE_MISC(float)
+
+void launch_mfma_probe_f32(const float* A, const float* B, float* D, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_probe_f32_kernel, dim3(1), dim3(64), 0, st, A, B, D);
 }
 
 void launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st) {

@@ -34,7 +34,8 @@ class GP:
     variance : signal variance sf2
     noise : observation-noise variance sn2 (added to the diagonal)
     jitter : extra diagonal term; default 1e-10 * variance
-    dtype : "float64" (implemented) | "float32"
+    dtype : "float64" | "float32" (everything, including the factorisation, in fp32:
+        the mixed-precision study of BASELINE.json configs[4]; not a 1e-6 path)
     device : HIP device ordinal (default: LOCAL_RANK or 0)
     block : Cholesky panel width nb (multiple of 128; 0 = library default 512)
     max_tries : jitter escalations (x10 each) before ``LinAlgError``
@@ -64,6 +65,7 @@ class GP:
             raise ValueError("need variance > 0 and noise >= 0")
         self.jitter = 1e-10 * self.variance if jitter is None else float(jitter)
         self.dtype = dtype
+        self._np_dtype = np.float64 if dtype == "float64" else np.float32
         self.block = int(block)
         self.max_tries = int(max_tries)
         if device is None:
@@ -134,8 +136,9 @@ class GP:
         if _is_torch(a):
             import torch
             t = a.detach()
-            if t.dtype != torch.float64:
-                t = t.to(torch.float64)
+            tdt = torch.float64 if self.dtype == "float64" else torch.float32
+            if t.dtype != tdt:
+                t = t.to(tdt)
             t = t.contiguous()
             if t.is_cuda:
                 if t.device.index != self.device:
@@ -143,7 +146,7 @@ class GP:
                 torch.cuda.current_stream(t.device).synchronize()
                 return C.c_void_p(t.data_ptr()), _abi.MEM_DEVICE, t, t.device, tuple(t.shape)
             a = t.numpy()
-        arr = np.ascontiguousarray(a, dtype=np.float64)
+        arr = np.ascontiguousarray(a, dtype=self._np_dtype)
         return C.c_void_p(arr.ctypes.data), _abi.MEM_HOST, arr, None, arr.shape
 
     # -- API ----------------------------------------------------------------------------
@@ -196,13 +199,14 @@ class GP:
         mshape = (M,) if self._y1d else (M, self._k)
         if devq is not None:
             import torch
-            mean = torch.empty(mshape, dtype=torch.float64, device=devq)
-            var = torch.empty((M,), dtype=torch.float64, device=devq) if return_var else None
+            tdt = torch.float64 if self.dtype == "float64" else torch.float32
+            mean = torch.empty(mshape, dtype=tdt, device=devq)
+            var = torch.empty((M,), dtype=tdt, device=devq) if return_var else None
             pm = C.c_void_p(mean.data_ptr())
             pv = C.c_void_p(var.data_ptr()) if return_var else None
         else:
-            mean = np.empty(mshape, dtype=np.float64)
-            var = np.empty((M,), dtype=np.float64) if return_var else None
+            mean = np.empty(mshape, dtype=self._np_dtype)
+            var = np.empty((M,), dtype=self._np_dtype) if return_var else None
             pm = C.c_void_p(mean.ctypes.data)
             pv = C.c_void_p(var.ctypes.data) if return_var else None
         self._check(self._lib.gpx_predict(self._h, pq, M, pm, pv, kq))
@@ -217,7 +221,7 @@ class GP:
         if not self._fitted:
             raise RuntimeError("no fit")
         if self._alpha is None:
-            out = np.empty((self._N, self._k), dtype=np.float64)
+            out = np.empty((self._N, self._k), dtype=self._np_dtype)
             self._check(self._lib.gpx_get_alpha(self._h, C.c_void_p(out.ctypes.data)))
             self._alpha = out[:, 0].copy() if self._y1d else out
         return self._alpha
@@ -233,7 +237,7 @@ class GP:
         if _is_torch(y):
             y = y.detach().cpu().numpy()
         Y = np.asarray(y, dtype=np.float64).reshape(self._N, -1)
-        A = self.alpha_.reshape(self._N, -1)
+        A = self.alpha_.reshape(self._N, -1).astype(np.float64)
         n, k = Y.shape
         return float(-0.5 * np.sum(Y * A) - 0.5 * k * self.log_det_
                      - 0.5 * n * k * np.log(2.0 * np.pi))

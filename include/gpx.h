@@ -85,7 +85,9 @@ const char* gpx_last_error(gpx_handle* h); /* h may be NULL: last error of gpx_c
 
 /* ---- hot path (SURVEY.md §8 rows a1,a3,a4 = fit; a2,a5,a6 = predict) --------- */
 /* K = sf2 k(X,X) + (sn2+jitter) I;  L = chol(K);  alpha = L^-T L^-1 y.
- * X (N,d), y (N,k) row-major, dtype of the handle.  lengthscale: n_ls = 1 or d. */
+ * X (N,d), y (N,k) row-major, in the dtype of the handle (GPX_F64: double, GPX_F32: float —
+ * everything including the factorisation then runs in fp32: config 5, the precision
+ * study; unsharded handles only).  lengthscale: n_ls = 1 or d. */
 int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
             const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter,
             int32_t mem_kind, int64_t* info);
@@ -138,6 +140,8 @@ int gpx_gemm_nt(double* C, int64_t m, int64_t n, const double* A, const double* 
 /* fp64 MFMA layout probe: D (16,16) = A (16,4) B (4,16) through one
  * v_mfma_f64_16x16x4_f64. */
 int gpx_mfma_probe(const double* A, const double* B, double* D);
+/* the same through one v_mfma_f32_16x16x4_f32 (different accumulator row map). */
+int gpx_mfma_probe_f32(const float* A, const float* B, float* D);
 /* microbenchmarks quoted beside the rooflines: sustained fp64 MFMA
  * TFLOP/s of a register-resident loop and HBM GB/s of a streaming copy. */
 int gpx_microbench(double* mfma_tflops, double* copy_gbs);

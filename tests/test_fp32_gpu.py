@@ -1,0 +1,38 @@
+"""GPU: the fp32 instantiation of the whole path (BASELINE.json configs[4], "fp32 + ARD
+lengthscales — mixed-precision tolerance study").  Not a 1e-6 path: every kernel,
+including the Cholesky, runs in fp32, so the error against the fp64 oracle is
+~cond(K) * 6e-8.  The tests pin (i) that the fp32 kernels compute the right thing on a
+well-conditioned problem and (ii) the error level the study reports."""
+import numpy as np
+import pytest
+
+from gaussianprocesspathmodelling_amd import GP
+from oracle.gp_oracle import OracleGP, synthetic_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,M,kernel,ls,noise", [
+    (1000, 200, "rbf", (0.3, 0.2, 0.25), 1e-1),
+    (2500, 130, "matern52", (0.3, 0.2, 0.25), 1e-2),
+    (129, 64, "rbf", 0.5, 1e-1),
+])
+def test_fp32_path_tracks_fp64_oracle(N, M, kernel, ls, noise):
+    X, y, Xs = synthetic_problem(N, 3, M, seed=N)
+    ref = OracleGP(kernel, ls, 1.5, noise, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    with GP(kernel, ls, 1.5, noise, jitter=0.0, dtype="float32") as gp:
+        mean, var = gp.fit(X, y).predict(Xs)
+        assert gp.info_ == 0
+        assert mean.dtype == np.float32 and var.dtype == np.float32 and gp.alpha_.dtype == np.float32
+        em = np.max(np.abs(mean - mr)) / np.max(np.abs(mr))
+        ev = np.max(np.abs(var - vr)) / 1.5
+        el = abs(gp.log_det_ - ref.log_det_) / abs(ref.log_det_)
+        print(f"fp32 N={N} {kernel}: mean err {em:.2e} (of max|mean|), var err {ev:.2e} (of sf2), logdet rel {el:.2e}")
+        assert em <= 2e-3 and ev <= 2e-3 and el <= 1e-3
+
+
+def test_fp32_rejects_sharding():
+    from gaussianprocesspathmodelling_amd import GpxError
+    with pytest.raises(GpxError):
+        GP("rbf", 0.3, dtype="float32", world=2, rank=0, comm="host")

@@ -123,3 +123,13 @@ def test_potrf_reports_first_bad_pivot(gpx):
     info = C.c_int64(0)
     assert gpx.gpx_potrf(_abi.dptr(A), n, 128, C.byref(info)) == 0
     assert info.value == 151
+
+
+def test_mfma_f32_layout(gpx):
+    """v_mfma_f32_16x16x4_f32: same A/B lane maps, accumulator rows 4*(l>>4)+r."""
+    rng = np.random.default_rng(1)
+    A = rng.integers(-8, 9, (16, 4)).astype(np.float32)
+    B = rng.integers(-8, 9, (4, 16)).astype(np.float32)
+    D = np.zeros((16, 16), dtype=np.float32)
+    assert gpx.gpx_mfma_probe_f32(A.ctypes.data, B.ctypes.data, D.ctypes.data) == 0
+    assert np.array_equal(D, A @ B)
