@@ -65,6 +65,7 @@ SIGNATURES = {
     "gpx_comm_unique_id": (C.c_int, [_P]),
     "gpx_comm_init": (C.c_int, [_P, _P]),
     "gpx_comm_init_host": (C.c_int, [_P, C.POINTER(GpxHostComm)]),
+    "gpx_path_distance": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, _P, C.c_int32]),
     "gpx_kernel_matrix": (C.c_int, [C.c_int32, _PD, C.c_int64, _PD, C.c_int64, C.c_int32, _PD,
                                     C.c_int32, C.c_double, C.c_double, _PD]),
     "gpx_potrf": (C.c_int, [_PD, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),

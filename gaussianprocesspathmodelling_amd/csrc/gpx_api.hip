@@ -768,6 +768,35 @@ done:
   return rc;
 }
 
+int gpx_path_distance(const double* paths, int64_t P, const double* cents, int64_t C, int32_t L,
+                      double* D, int32_t mem_kind) {
+  if (!paths || !cents || !D || P <= 0 || C <= 0 || L <= 0 || L > 64) return GPX_E_ARG;
+  if (mem_kind != GPX_MEM_HOST && mem_kind != GPX_MEM_DEVICE) return GPX_E_ARG;
+  Scratch sc;
+  if (!sc.ok) return GPX_E_HIP;
+  hipStream_t st = sc.h.st;
+  const bool host = mem_kind == GPX_MEM_HOST;
+  double *dp = nullptr, *dc = nullptr, *dD = nullptr;
+  int rc = GPX_OK;
+  TCHK(hipMalloc(&dc, (size_t)C * L * 16));
+  TCHK(hipMemcpyAsync(dc, cents, (size_t)C * L * 16, host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+  if (host) {
+    TCHK(hipMalloc(&dp, (size_t)P * L * 16));
+    TCHK(hipMalloc(&dD, (size_t)P * C * 8));
+    TCHK(hipMemcpyAsync(dp, paths, (size_t)P * L * 16, hipMemcpyHostToDevice, st));
+  }
+  for (int64_t c0 = 0; c0 < C; c0 += 64)
+    launch_path_distance(host ? dp : paths, P, dc + c0 * L * 2, (int)std::min<int64_t>(64, C - c0), L,
+                         (host ? dD : D) + c0, C, st);
+  if (host) TCHK(hipMemcpyAsync(D, dD, (size_t)P * C * 8, hipMemcpyDeviceToHost, st));
+  TCHK(hipStreamSynchronize(st));
+  TCHK(hipGetLastError());
+done:
+  for (double* p : {dp, dc, dD})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
 int gpx_mfma_probe_f32(const float* A, const float* B, float* D) {
   if (!A || !B || !D) return GPX_E_ARG;
   Scratch sc;

@@ -81,6 +81,11 @@ void launch_mfma_probe_f32(const float* A, const float* B, float* D, hipStream_t
 void launch_mfma_loop(double* sink, int iters, int blocks, hipStream_t st);
 void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st);
 
+// ---- path distance (gpx_paths.hip) -----------------------------------------------------------
+// D (P, ldd)[p][c] = sum_i ||paths[p][i] - cents[c][i]||, paths (P, L, 2), cents (C <= 64, L <= 64, 2)
+void launch_path_distance(const double* paths, int64_t P, const double* cents, int C, int L, double* D,
+                          int64_t ldd, hipStream_t st);
+
 // ---- row-block-cyclic shard helpers (gpx_misc.hip, fp64) ----------------------------------
 // A[i][i] = i < nvalid ? A[i][i] + add : 1   for i < n (diagonal of one local row block)
 void launch_fix_diag(double* A, int64_t lda, int n, int nvalid, double add, hipStream_t st);

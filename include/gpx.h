@@ -122,6 +122,14 @@ typedef struct gpx_host_comm {
 } gpx_host_comm;
 int gpx_comm_init_host(gpx_handle* h, const gpx_host_comm* vt);
 
+/* ---- batched path distance (reference: trajectories.calc_distance,
+ * GPmap.py:114-121, the inner loop of kmeansclustering GPmap.py:72-80) ---------------- */
+/* D (P,C)[p][c] = sum_{i<L} || paths[p][i] - cents[c][i] ||_2 with paths (P,L,2) and cents
+ * (C,L,2) arrays of (x,y), fp64, L <= 64.  mem_kind as in gpx_fit (device pointers must
+ * live on the current HIP device). */
+int gpx_path_distance(const double* paths, int64_t P, const double* cents, int64_t C, int32_t L,
+                      double* D, int32_t mem_kind);
+
 /* ---- kernel unit-test entry points (host buffers, fp64) ------------------------- */
 /* K (na,nb) = sf2 k(A,B) (+ diag_add on the diagonal when B == NULL, i.e. B = A). */
 int gpx_kernel_matrix(int32_t kernel, const double* A, int64_t na, const double* B, int64_t nb,
