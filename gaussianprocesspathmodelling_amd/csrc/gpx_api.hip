@@ -824,7 +824,8 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs) {
   double *sink = nullptr, *src = nullptr, *dst = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const int64_t count = (int64_t)1 << 28;  // 2 GiB per buffer
-  const int iters = 4096, blocks = 256 * 8;
+  const int iters = 4096;
+  const int blocks = getenv("GPX_MB_BLOCKS") ? atoi(getenv("GPX_MB_BLOCKS")) : 256 * 8;
   float ms = 0.f;
   int rc = GPX_OK;
   TCHK(hipMalloc(&sink, 64));

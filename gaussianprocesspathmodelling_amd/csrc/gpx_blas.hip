@@ -223,16 +223,18 @@ __device__ __forceinline__ void gemm_tile_g(const T* A, int64_t lda, const T* B,
   for (int q = 0; q < IB; ++q) GPX_GLDS16(gb[q], lb + q * RQ);
   __syncthreads();
 
+  // Per k-step: 8 first-half fragment reads, then the MFMAs with everything else issued in
+  // their shadow: the second-half fragment reads inside the first quarter of the burst, the
+  // DMA of step t+1 inside the second (sched_group_barrier: 0x8 MFMA, 0x100 DS read, 0x20
+  // VMEM read).  Measured on the SYRK: 65.1 TF with DMA + all 16 reads clumped before the
+  // burst -> 67.9 TF interleaved.  (A 4-stage, one-workgroup-per-CU variant with counted
+  // vmcnt and a second fragment set reached only 59.6 TF: per-wave wait time fell from 8.7 %
+  // to 3.7 %, but nothing covers the tile epilogue and the launch tail any more.)  The DMA is unconditional (clamped to the last step, landing in
+  // the buffer nobody reads again) so that the loop body stays one basic block.
+  constexpr int HALF = SL * MT * NT;  // MFMAs per half step
   const int KT = K / BK;
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < KT) {
-      const int64_t ko = (int64_t)(kt + 1) * BK;
-#pragma unroll
-      for (int q = 0; q < IA; ++q) GPX_GLDS16(ga[q] + ko, la + (buf ^ 1) * S::A_STAGE + q * RQ);
-#pragma unroll
-      for (int q = 0; q < IB; ++q) GPX_GLDS16(gb[q] + ko, lb + (buf ^ 1) * S::B_STAGE + q * RQ);
-    }
     const T* Ab = As + buf * S::A_STAGE;
     const T* Bb = Bs + buf * S::B_STAGE;
     slot_t a0[MT], b0[NT], a1[MT], b1[NT];
@@ -244,6 +246,13 @@ __device__ __forceinline__ void gemm_tile_g(const T* A, int64_t lda, const T* B,
     for (int m = 0; m < MT; ++m) a1[m] = *reinterpret_cast<const slot_t*>(Ab + a_off1 + m * 16 * BK);
 #pragma unroll
     for (int n = 0; n < NT; ++n) b1[n] = *reinterpret_cast<const slot_t*>(Bb + b_off1 + n * 16 * BK);
+    {
+      const int64_t ko = (int64_t)(kt + 1 < KT ? kt + 1 : kt) * BK;
+#pragma unroll
+      for (int q = 0; q < IA; ++q) GPX_GLDS16(ga[q] + ko, la + (buf ^ 1) * S::A_STAGE + q * RQ);
+#pragma unroll
+      for (int q = 0; q < IB; ++q) GPX_GLDS16(gb[q] + ko, lb + (buf ^ 1) * S::B_STAGE + q * RQ);
+    }
 #pragma unroll
     for (int s = 0; s < SL; ++s)
 #pragma unroll
@@ -256,6 +265,20 @@ __device__ __forceinline__ void gemm_tile_g(const T* A, int64_t lda, const T* B,
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = Num<T>::mfma(a1[m][s], b1[n][s], acc[m][n]);
+    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // first-half fragments first
+    // first quarter of the burst: one second-half fragment read per 2 MFMAs; second
+    // quarter: the DMA of step t+1, one per 2 MFMAs; the second half is pure MFMA (covers
+    // the DMA latency together with the co-resident workgroup's burst)
+#pragma unroll
+    for (int i = 0; i < MT + NT; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x8, HALF / (2 * (MT + NT)), 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < IA + IB; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x8, HALF / (2 * (IA + IB)), 0);
+      __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+    }
     // keep the MFMAs ABOVE the barrier: hipcc otherwise sinks them below the vmcnt(0)
     // drain of __syncthreads() and the DMA latency is exposed on every k-step
     __builtin_amdgcn_sched_barrier(0);
@@ -360,11 +383,9 @@ __device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, int tiles_
 
 // ---- C op= A * B^T --------------------------------------------------------------
 template <typename T, int BT, bool TRI, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(T* __restrict__ C, int64_t ldc,
-                                                         const T* __restrict__ A, int64_t lda,
-                                                         const T* __restrict__ B, int64_t ldb,
-                                                         int tiles_m, int tiles_n, int sh,
-                                                         int mask_lower, BcMask bc, int K) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
+    T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+    int64_t ldb, int tiles_m, int tiles_n, int sh, int mask_lower, BcMask bc, int K) {
   __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
   const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
   int ti, tj;
@@ -637,6 +658,9 @@ int64_t rect_grid(int64_t tm, int64_t tn, int& sh) {
   return ((tm + sh - 1) / sh) * ((tn + sw - 1) / sw) * 64;
 }
 
+// experiment knob: extra dynamic LDS per block (forces fewer workgroups per CU)
+const int g_dyn_lds = getenv("GPX_GEMM_DYNLDS") ? atoi(getenv("GPX_GEMM_DYNLDS")) : 0;
+
 template <typename T, int BT>
 void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
                       int64_t n, int64_t k, int lower, int mode, BcMask bc, hipStream_t st) {
@@ -646,17 +670,17 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
     const int64_t ts = (tm + 7) / 8;
     dim3 grid((unsigned)(ts * (ts + 1) / 2 * 64));
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 0>), grid, block, g_dyn_lds, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 1>), grid, block, g_dyn_lds, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
   } else {  // rectangle; lower == 2: masked to tj <= ti; lower == 3: block-cyclic mask
     int sh;
     dim3 grid((unsigned)rect_grid(tm, tn, sh));
     const int mask = lower == 2 ? 1 : lower == 3 ? 2 : 0;
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 0>), grid, block, g_dyn_lds, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 1>), grid, block, g_dyn_lds, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
   }
 }
 

@@ -76,6 +76,12 @@ def test_gemm_nt(gpx, m, n, k, lower):
         assert err[done].max() <= 4 * k * EPS
         assert np.array_equal(Cg[~done], C0[~done]), "tiles above the diagonal must be untouched"
     else:
+        if not err.max() <= 4 * k * EPS:   # diagnostics: where is it wrong?
+            bad = err > 4 * k * EPS
+            rows, cols = np.unique(np.nonzero(bad)[0]), np.unique(np.nonzero(bad)[1])
+            print(f"gemm_nt diag: {bad.sum()} bad of {bad.size}; rows {rows[:32]} (n={len(rows)}); "
+                  f"cols {cols[:32]} (n={len(cols)}); untouched={int(np.sum(Cg == C0))}; "
+                  f"nan={int(np.isnan(Cg).sum())}")
         assert err.max() <= 4 * k * EPS
 
 
