@@ -392,9 +392,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   if (!tile_coords<TRI>(lin, tiles_m, tiles_n, sh, mask_lower, bc, ti, tj)) return;
   typename Num<T>::v4 acc[BT / 32][BT / 32];
   zero_acc(acc);
+  T* Ct = C + (int64_t)ti * BT * ldc + (int64_t)tj * BT;
   gemm_tile_g<T, BT, BT>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc,
                          smem);
-  store_tile<T, BT, BT, MODE>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
+  // (a software-pipelined epilogue — strips of C prefetched / kept in flight — measured
+  //  0.5-1 % slower than this plain strip-by-strip one: it pushes the kernel to 256 VGPRs)
+  store_tile<T, BT, BT, MODE>(Ct, ldc, acc);
 }
 
 // ---- C -= A * B, B stored [k][n]; 64x64 tiles --------------------------------------
