@@ -24,7 +24,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                  summed over the launches of the timed steps (library events on the
                  library's stream, GPX_FLAG_PROFILE)
   cpu_baseline — the NumPy/SciPy oracle (oracle/gp_oracle.py) timed on this host's cores
-                 on a bounded sample (N=8192, same generator), rank 0, N=1 only
+                 on a bounded sample (N=24576, same generator, ~20 s), rank 0, N=1 only
 """
 from __future__ import annotations
 
@@ -54,7 +54,7 @@ def synthetic(N, d, M, seed):
     return X, y, Xs
 
 
-def cpu_baseline(n_sample=8192):
+def cpu_baseline(n_sample=24576):
     """Oracle fit+predict on the host cores, bounded sample (about 10-30 s)."""
     import numpy as np
     from oracle.gp_oracle import OracleGP
@@ -82,7 +82,9 @@ def cpu_baseline(n_sample=8192):
                    f"N={n_sample} d={DIM} M={M_TEST} RBF fp64, same generator: fit {t1 - t0:.2f} s "
                    f"(kbuild {tm['kbuild']:.0f} ms, chol {tm['chol']:.0f} ms, solve {tm['solve']:.0f} ms), "
                    f"predict {t2 - t1:.2f} s; phase-wise extrapolation to N={N_TRAIN}: "
-                   f"{est:.0f} s/step = {(N_TRAIN + M_TEST) / est:.1f} points/s"),
+                   f"{est:.0f} s/step = {(N_TRAIN + M_TEST) / est:.1f} points/s (a one-off FULL-size "
+                   f"oracle run on a pool host took 165 s = 422 points/s: "
+                   f"profiles/r01_c3_full_oracle_parity.json)"),
         "extrapolated_points_per_s_at_workload": (N_TRAIN + M_TEST) / est,
     }
 

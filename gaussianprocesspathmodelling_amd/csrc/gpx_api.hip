@@ -71,6 +71,8 @@ struct gpx_handle {
   DevBuf Q, Qs, VT, MT, var, meanout;
   // row-block shard (world > 1)
   Comm* comm = nullptr;  // RCCL or host-callback transport (gpx_shard.inc)
+  bool border = true;  // right-hand sides ride through the factorisation as extra rows
+  void* alphaT = nullptr;  // alpha^T (64 x ld): inside the K buffer (bordered rows) or YT (shard)
   int nb_shard = 512;  // distribution block = panel width of the sharded factorisation
   int64_t nloc = 0, ldy = 0;
   DevBuf G, Pglob, Dbuf, Sbuf, YTloc, Cneg, Sv;
@@ -184,9 +186,13 @@ void diag_enqueue(T* A, int64_t ld, int64_t o, int nbp, T* Winv, int* info, int6
   }
 }
 
+// nx extra rows (0 or a multiple of 64) directly below row n-1 ride along through every
+// panel solve and trailing update without being factorised: with the right-hand sides
+// stored there as rows ("bordered matrix"), they leave the factorisation as
+// z^T = (L^-1 y)^T — the forward substitution costs no serial pass of its own.
 template <typename T>
 void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T* P0, T* P1,
-                  int64_t ldp, int* info, int64_t gidx0, bool profile) {
+                  int64_t ldp, int* info, int64_t gidx0, bool profile, int64_t nx = 0) {
   hipStream_t s0 = h->st, s1 = h->st2;
   T* Pbuf[2] = {P0, P1};
   // prologue: panel 0 on the main stream
@@ -196,9 +202,9 @@ void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T
       PhaseScope ps(h, &h->tm.chol_diag, profile);
       diag_enqueue(A, ld, 0, nb0, Winv, info, gidx0, s0);
     }
-    if (n - nb0 > 0) {
+    if (n - nb0 + nx > 0) {
       PhaseScope ps(h, &h->tm.chol_trsm, profile);
-      launch_trsm_rlt<T>(A + (int64_t)nb0 * ld, ld, n - nb0, A, ld, Winv, nb0, Pbuf[0], ldp, s0);
+      launch_trsm_rlt<T>(A + (int64_t)nb0 * ld, ld, n - nb0 + nx, A, ld, Winv, nb0, Pbuf[0], ldp, s0);
     }
   }
   int step = 0;
@@ -207,7 +213,7 @@ void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T
     const int64_t t0 = o + nbp;          // first trailing row/col
     const int64_t ntrail = n - t0;
     if (ntrail <= 0) break;
-    T* Pc = Pbuf[step & 1];         // panel of this step, rows [t0, n)
+    T* Pc = Pbuf[step & 1];              // panel of this step, rows [t0, n + nx)
     T* Pn = Pbuf[(step + 1) & 1];
     const int nbn = (int)std::min<int64_t>(nb, ntrail);  // width of the next panel
     const int64_t nrest = ntrail - nbn;
@@ -215,6 +221,11 @@ void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T
     {  // STRIP: rows [t0, n) x cols [t0, t0+nbn), tiles on/below the diagonal
       PhaseScope ps(h, &h->tm.chol_strip, profile);
       launch_gemm_nt<T>(tile, A + t0 * ld + t0, ld, Pc, ldp, Pc, ldp, ntrail, nbn, nbp, 2, 0, s0);
+      // bordered rows [n, n+nx) x all trailing cols: their own small launch, so that the
+      // SYRK grids (and their XCD balance) stay exactly those of the plain factorisation
+      if (nx > 0)
+        launch_gemm_nt<T>(nx % 128 == 0 && ntrail % 128 == 0 ? 128 : 64, A + n * ld + t0, ld,
+                          Pc + ntrail * ldp, ldp, Pc, ldp, nx, ntrail, nbp, 0, 0, s0);
     }
     hipEvent_t e_strip = next_event(h), e_panel = next_event(h);
     (void)hipEventRecord(e_strip, s0);
@@ -224,17 +235,17 @@ void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T
         PhaseScope ps(h, &h->tm.chol_diag, profile, s1);
         diag_enqueue(A, ld, t0, nbn, Winv, info, gidx0, s1);
       }
-      if (nrest > 0) {
+      if (nrest + nx > 0) {
         PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
-        launch_trsm_rlt<T>(A + (t0 + nbn) * ld + t0, ld, nrest, A + t0 * ld + t0, ld,
-                        Winv + (t0 / KB) * (KB * KB), nbn, Pn, ldp, s1);
+        launch_trsm_rlt<T>(A + (t0 + nbn) * ld + t0, ld, nrest + nx, A + t0 * ld + t0, ld,
+                           Winv + (t0 / KB) * (KB * KB), nbn, Pn, ldp, s1);
       }
     }
     (void)hipEventRecord(e_panel, s1);
     if (nrest > 0) {  // REST: lower triangle of the trailing matrix beyond the strip
       PhaseScope ps(h, &h->tm.chol_syrk, profile);
       launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + (t0 + nbn), ld, Pc + (int64_t)nbn * ldp, ldp,
-                     Pc + (int64_t)nbn * ldp, ldp, nrest, nrest, nbp, 1, 0, s0);
+                        Pc + (int64_t)nbn * ldp, ldp, nrest, nrest, nbp, 1, 0, s0);
       h->tm.syrk_flops += (double)nrest * (double)(nrest + 1) * (double)nbp;
       h->tm.syrk_launches += 1;
     }
@@ -242,20 +253,47 @@ void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T
   }
 }
 
-// XT (rows x n, ld) <- XT * L^-T   (i.e. X <- L^-1 X for X = XT^T), block forward substitution
+// XT (rows x n, ld) <- XT * L^-T   (i.e. X <- L^-1 X for X = XT^T), block forward substitution.
+// With many right-hand sides (rows >= 128: the variance TRSM) the same one-panel
+// look-ahead as the factorisation: the update of block p is split into the STRIP (the
+// columns of block p+1) and the REST; the high-priority stream solves block p+1 while
+// the main stream runs the rest of update p (disjoint columns of XT).
 template <typename T>
 void solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld, int64_t n, int nb,
                        const T* Winv) {
-  hipStream_t st = h->st;
+  hipStream_t s0 = h->st, s1 = h->st2;
   const int tile = (rows % 128 == 0) ? 128 : 64;
+  if (rows < 128 || !s1) {
+    for (int64_t o = 0; o < n; o += nb) {
+      const int nbp = (int)std::min<int64_t>(nb, n - o);
+      launch_trsm_rlt<T>(XT + o, ld, rows, L + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, nullptr,
+                         0, s0);
+      const int64_t ntrail = n - (o + nbp);
+      if (ntrail > 0)
+        launch_gemm_nt<T>((ntrail % 128 == 0) ? tile : 64, XT + o + nbp, ld, XT + o, ld,
+                          L + (o + nbp) * ld + o, ld, rows, ntrail, nbp, 0, 0, s0);
+    }
+    return;
+  }
+  launch_trsm_rlt<T>(XT, ld, rows, L, ld, Winv, (int)std::min<int64_t>(nb, n), nullptr, 0, s0);
   for (int64_t o = 0; o < n; o += nb) {
     const int nbp = (int)std::min<int64_t>(nb, n - o);
-    launch_trsm_rlt<T>(XT + o, ld, rows, L + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, nullptr,
-                    0, st);
-    const int64_t ntrail = n - (o + nbp);
-    if (ntrail > 0)
-      launch_gemm_nt<T>((ntrail % 128 == 0) ? tile : 64, XT + o + nbp, ld, XT + o, ld,
-                     L + (o + nbp) * ld + o, ld, rows, ntrail, nbp, 0, 0, st);
+    const int64_t t0 = o + nbp, ntrail = n - t0;
+    if (ntrail <= 0) break;
+    const int nbn = (int)std::min<int64_t>(nb, ntrail);
+    const int64_t nrest = ntrail - nbn;
+    const int tl = (nbn % 128 == 0 && nrest % 128 == 0) ? tile : 64;
+    launch_gemm_nt<T>(tl, XT + t0, ld, XT + o, ld, L + t0 * ld + o, ld, rows, nbn, nbp, 0, 0, s0);  // STRIP
+    hipEvent_t e_strip = next_event(h), e_panel = next_event(h);
+    (void)hipEventRecord(e_strip, s0);
+    (void)hipStreamWaitEvent(s1, e_strip, 0);
+    launch_trsm_rlt<T>(XT + t0, ld, rows, L + t0 * ld + t0, ld, Winv + (t0 / KB) * (KB * KB), nbn, nullptr,
+                       0, s1);
+    (void)hipEventRecord(e_panel, s1);
+    if (nrest > 0)  // REST
+      launch_gemm_nt<T>(tl, XT + t0 + nbn, ld, XT + o, ld, L + (t0 + nbn) * ld + o, ld, rows, nrest, nbp, 0,
+                        0, s0);
+    (void)hipStreamWaitEvent(s0, e_panel, 0);
   }
 }
 
@@ -315,15 +353,16 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   if ((rc = ensure(h, h->Y, (size_t)N * k * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->Xs, (size_t)Npad * d * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->ls, 32 * 8))) return rc;
-  if ((rc = ensure(h, h->K, (size_t)Npad * ld * sizeof(T)))) return rc;
+  const int64_t NX = RHS_ROWS;  // bordered rows: the right-hand sides ride through the factorisation
+  if ((rc = ensure(h, h->K, (size_t)(Npad + NX) * ld * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->Winv, (size_t)(Npad / KB) * KB * KB * sizeof(T)))) return rc;
-  if ((rc = ensure(h, h->P, (size_t)2 * Npad * ldp * sizeof(T)))) return rc;
-  if ((rc = ensure(h, h->YT, (size_t)RHS_ROWS * ld * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->P, (size_t)2 * (Npad + NX) * ldp * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->scalars, 64))) return rc;
   if ((rc = ensure(h, h->info, 64))) return rc;
 
   T* dK = (T*)h->K.p;
-  T* dYT = (T*)h->YT.p;
+  T* dYT = dK + Npad * ld;  // rows [Npad, Npad + NX) of the K buffer: y^T, then z^T, then alpha^T
+  h->alphaT = dYT;
   int* dInfo = (int*)h->info.p;
   {
     PhaseScope total(h, &tm.fit_total);
@@ -344,13 +383,14 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
     }
     {
       PhaseScope ps(h, &tm.chol);
+      launch_pack_rhs<T>((const T*)h->Y.p, N, k, dYT, ld, Npad, (int)NX, h->st);
       chol_enqueue<T>(h, dK, ld, Npad, h->nb, (T*)h->Winv.p, (T*)h->P.p,
-                   (T*)h->P.p + Npad * ldp, ldp, dInfo, 0, profile);
+                      (T*)h->P.p + (Npad + NX) * ldp, ldp, dInfo, 0, profile, h->border ? NX : 0);
     }
-    {
+    {  // bordered: the forward substitution happened inside the factorisation; only L^T remains
       PhaseScope ps(h, &tm.solve);
-      launch_pack_rhs<T>((const T*)h->Y.p, N, k, dYT, ld, Npad, RHS_ROWS, h->st);
-      solve_fwd_enqueue<T>(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const T*)h->Winv.p);
+      if (!h->border)
+        solve_fwd_enqueue<T>(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const T*)h->Winv.p);
       solve_bwd_enqueue<T>(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const T*)h->Winv.p);
     }
     {
@@ -401,7 +441,7 @@ int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var
     {
       // mean^T (64 x Mpad) = alpha^T (64 x Npad) * K*^T
       PhaseScope ps(h, &tm.mean);
-      launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->YT.p, ld, dVT, ld, RHS_ROWS, Mpad,
+      launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->alphaT, ld, dVT, ld, RHS_ROWS, Mpad,
                      Npad, 0, 1, h->st);
       launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, k, 1.0, (T*)h->meanout.p, h->st);
     }
@@ -431,7 +471,7 @@ template <typename T>
 int alpha_impl(gpx_handle* h, void* out) {
   int rc;
   if ((rc = ensure(h, h->meanout, (size_t)h->N * h->k * sizeof(T)))) return rc;
-  launch_unpack_rhs<T>((const T*)h->YT.p, h->ld, h->N, h->k, 1.0, (T*)h->meanout.p, h->st);
+  launch_unpack_rhs<T>((const T*)h->alphaT, h->ld, h->N, h->k, 1.0, (T*)h->meanout.p, h->st);
   HIPCHK(h, hipMemcpyAsync(out, h->meanout.p, (size_t)h->N * h->k * sizeof(T), hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipStreamSynchronize(h->st));
   return GPX_OK;
@@ -479,6 +519,7 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
   if (!h) return fail(nullptr, GPX_E_NOMEM, "gpx_create: out of host memory");
   h->cfg = *cfg;
   h->nb = nb;
+  if (const char* e = getenv("GPX_NO_BORDER")) h->border = atoi(e) == 0;
   if (const char* e = getenv("GPX_NB_SHARD")) h->nb_shard = atoi(e);
   if (h->nb_shard < 128 || h->nb_shard > 2048 || h->nb_shard % 128 != 0) h->nb_shard = 512;
   if (const char* e = getenv("GPX_NB_SOLVE")) h->nb_solve = atoi(e);

@@ -367,7 +367,7 @@ __device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, int tiles_
     tri_coords(st, sr, sc);
     ti = sr * 8 + (inner >> 3);
     tj = sc * 8 + (inner & 7);
-    return ti < tiles_m && tj <= ti;
+    return ti < tiles_m && tj <= ti && tj < tiles_n;  // tiles_n < tiles_m: bordered extra rows
   } else {
     const int sw = 64 / sh;  // sh in {1, 8}
     const int sn = (tiles_n + sw - 1) / sw;
