@@ -54,6 +54,28 @@ def synthetic(N, d, M, seed):
     return X, y, Xs
 
 
+def pmc_traffic():
+    """HBM bytes per SYRK launch from the committed rocprofv3 PMC passes of this same command
+    (separate --pmc FETCH_SIZE / WRITE_SIZE runs; KiB units; FETCH_SIZE x2 on gfx950 for the
+    16-B/lane streaming reads — MI355X_MICROARCH.md §HBM).  None if no summary is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.csv")))
+    if not files:
+        return None, None
+    fetch = write = None
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if "gemm_nt_kernel<double, 128, true, 0>" in row["Kernel_Name"]:
+                if row["Counter_Name"] == "FETCH_SIZE":
+                    fetch = float(row["mean"])
+                elif row["Counter_Name"] == "WRITE_SIZE":
+                    write = float(row["mean"])
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1])
+
+
 def cpu_baseline(n_sample=24576):
     """Oracle fit+predict on the host cores, bounded sample (about 10-30 s)."""
     import numpy as np
@@ -205,7 +227,8 @@ def main():
             "roofline": {
                 "kernel": "gemm_nt_kernel<128,LOWER> (trailing SYRK of the blocked Cholesky)",
                 "bound": "mfma", "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": pmc_traffic()[0],
+                "traffic_source": pmc_traffic()[1],
                 "launches": launches,
                 "flops_per_launch": acc["syrk_flops"] / max(1, launches),
                 "avg_launch_ms": syrk_ms / max(1, launches)},
