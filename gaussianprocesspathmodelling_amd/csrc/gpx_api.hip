@@ -519,7 +519,6 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
   if (!h) return fail(nullptr, GPX_E_NOMEM, "gpx_create: out of host memory");
   h->cfg = *cfg;
   h->nb = nb;
-  if (const char* e = getenv("GPX_NO_BORDER")) h->border = atoi(e) == 0;
   if (const char* e = getenv("GPX_NB_SHARD")) h->nb_shard = atoi(e);
   if (h->nb_shard < 128 || h->nb_shard > 2048 || h->nb_shard % 128 != 0) h->nb_shard = 512;
   if (const char* e = getenv("GPX_NB_SOLVE")) h->nb_solve = atoi(e);
@@ -571,6 +570,8 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->fitted = false;
   h->err.clear();
+  h->phases.clear();  // an earlier call that failed mid-way must not leak its event pairs
+  h->ev_used = 0;
   if (h->cfg.world > 1 || h->comm)  // a 1-rank communicator also takes the sharded schedule
     return shard_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
 
@@ -587,6 +588,8 @@ int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var,
     return fail(h, GPX_E_ARG, "gpx_predict: bad mem_kind");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->err.clear();
+  h->phases.clear();
+  h->ev_used = 0;
   if (h->cfg.world > 1 || h->comm) return shard_predict(h, Xq, M, mean, var, mem_kind);
   if (h->cfg.dtype == GPX_F32) return predict_impl<float>(h, Xq, M, mean, var, mem_kind);
   return predict_impl<double>(h, Xq, M, mean, var, mem_kind);
@@ -866,7 +869,7 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const int64_t count = (int64_t)1 << 28;  // 2 GiB per buffer
   const int iters = 4096;
-  const int blocks = getenv("GPX_MB_BLOCKS") ? atoi(getenv("GPX_MB_BLOCKS")) : 256 * 8;
+  const int blocks = 256 * 8;
   float ms = 0.f;
   int rc = GPX_OK;
   TCHK(hipMalloc(&sink, 64));

@@ -661,8 +661,6 @@ int64_t rect_grid(int64_t tm, int64_t tn, int& sh) {
   return ((tm + sh - 1) / sh) * ((tn + sw - 1) / sw) * 64;
 }
 
-// experiment knob: extra dynamic LDS per block (forces fewer workgroups per CU)
-const int g_dyn_lds = getenv("GPX_GEMM_DYNLDS") ? atoi(getenv("GPX_GEMM_DYNLDS")) : 0;
 
 template <typename T, int BT>
 void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
@@ -673,17 +671,17 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
     const int64_t ts = (tm + 7) / 8;
     dim3 grid((unsigned)(ts * (ts + 1) / 2 * 64));
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 0>), grid, block, g_dyn_lds, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 1>), grid, block, g_dyn_lds, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
   } else {  // rectangle; lower == 2: masked to tj <= ti; lower == 3: block-cyclic mask
     int sh;
     dim3 grid((unsigned)rect_grid(tm, tn, sh));
     const int mask = lower == 2 ? 1 : lower == 3 ? 2 : 0;
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 0>), grid, block, g_dyn_lds, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 1>), grid, block, g_dyn_lds, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
   }
 }
 
