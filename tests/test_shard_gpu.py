@@ -32,10 +32,12 @@ def test_sharded_schedule_single_rank_rccl(N, M, nb, monkeypatch):
         assert np.array_equal(gp.predict(Xs, return_var=False), mean)
 
 
-@pytest.mark.parametrize("world,kernel,nb", [(2, "rbf", 128), (3, "matern52", 128), (2, "rbf", 256)])
-def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb):
-    res = run_ranks("gpu", world, tmp_path, {"SHARD_KERNEL": kernel, "SHARD_NB": str(nb)}, timeout=600)
-    X, y, Xs = synthetic_problem(700, 3, 90, seed=77)
+@pytest.mark.parametrize("world,kernel,nb,N", [(2, "rbf", 128, 700), (3, "matern52", 128, 700),
+                                                 (2, "rbf", 256, 700), (4, "rbf", 512, 3300)])
+def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N):
+    res = run_ranks("gpu", world, tmp_path, {"SHARD_KERNEL": kernel, "SHARD_NB": str(nb), "SHARD_N": str(N)},
+                    timeout=600)
+    X, y, Xs = synthetic_problem(N, 3, 90, seed=77)
     ref = OracleGP(kernel, (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
     mr, vr = ref.predict(Xs)
     for r in res:
