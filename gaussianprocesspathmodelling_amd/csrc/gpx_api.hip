@@ -71,8 +71,10 @@ struct gpx_handle {
   DevBuf Q, Qs, VT, MT, var, meanout;
   // row-block shard (world > 1)
   Comm* comm = nullptr;  // RCCL or host-callback transport (gpx_shard.inc)
-  bool border = true;  // right-hand sides ride through the factorisation as extra rows
-  void* alphaT = nullptr;  // alpha^T (64 x ld): inside the K buffer (bordered rows) or YT (shard)
+  void* zT = nullptr;      // z^T = (L^-1 y)^T (64 x ld): the bordered rows of the K buffer
+  void* alphaT = nullptr;  // alpha^T (64 x ld): AT (computed on demand from z^T) or YT (shard)
+  bool alpha_ready = false;
+  DevBuf AT;
   int nb_shard = 512;  // distribution block = panel width of the sharded factorisation
   int64_t nloc = 0, ldy = 0;
   DevBuf G, Pglob, Dbuf, Sbuf, YTloc, Cneg, Sv;
@@ -361,8 +363,10 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   if ((rc = ensure(h, h->info, 64))) return rc;
 
   T* dK = (T*)h->K.p;
-  T* dYT = dK + Npad * ld;  // rows [Npad, Npad + NX) of the K buffer: y^T, then z^T, then alpha^T
-  h->alphaT = dYT;
+  T* dYT = dK + Npad * ld;  // rows [Npad, Npad + NX) of the K buffer: y^T, then z^T = (L^-1 y)^T
+  h->zT = dYT;
+  h->alphaT = nullptr;
+  h->alpha_ready = false;
   int* dInfo = (int*)h->info.p;
   {
     PhaseScope total(h, &tm.fit_total);
@@ -385,14 +389,12 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
       PhaseScope ps(h, &tm.chol);
       launch_pack_rhs<T>((const T*)h->Y.p, N, k, dYT, ld, Npad, (int)NX, h->st);
       chol_enqueue<T>(h, dK, ld, Npad, h->nb, (T*)h->Winv.p, (T*)h->P.p,
-                      (T*)h->P.p + (Npad + NX) * ldp, ldp, dInfo, 0, profile, h->border ? NX : 0);
+                      (T*)h->P.p + (Npad + NX) * ldp, ldp, dInfo, 0, profile, NX);
     }
-    {  // bordered: the forward substitution happened inside the factorisation; only L^T remains
-      PhaseScope ps(h, &tm.solve);
-      if (!h->border)
-        solve_fwd_enqueue<T>(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const T*)h->Winv.p);
-      solve_bwd_enqueue<T>(h, dYT, RHS_ROWS, dK, ld, Npad, h->nb_solve, (const T*)h->Winv.p);
-    }
+    // The forward substitution happened inside the factorisation (bordered rows).  The
+    // back substitution alpha = L^-T z is NOT on the fit+predict path: the posterior mean is
+    // K* K^-1 y = V^T z with V = L^-1 K*^T, which the variance path computes anyway;
+    // alpha is produced on demand (gpx_get_alpha, mean-only predict): ensure_alpha().
     {
       PhaseScope ps(h, &tm.logdet);
       launch_logdet<T>(dK, ld, Npad, (double*)h->scalars.p, h->st);
@@ -406,6 +408,22 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   collect_phases(h);
   *info = (hinfo == INT_MAX) ? 0 : (int64_t)hinfo;
   h->fitted = (*info == 0);
+  return GPX_OK;
+}
+
+// alpha^T = z^T L^-1 on a copy of the bordered rows (z stays available for V^T z)
+template <typename T>
+int ensure_alpha(gpx_handle* h) {
+  if (h->alpha_ready) return GPX_OK;
+  int rc;
+  if ((rc = ensure(h, h->AT, (size_t)RHS_ROWS * h->ld * sizeof(T)))) return rc;
+  PhaseScope ps(h, &h->tm.solve);
+  HIPCHK(h, hipMemcpyAsync(h->AT.p, h->zT, (size_t)RHS_ROWS * h->ld * sizeof(T), hipMemcpyDeviceToDevice,
+                           h->st));
+  solve_bwd_enqueue<T>(h, (T*)h->AT.p, RHS_ROWS, (const T*)h->K.p, h->ld, h->Npad, h->nb_solve,
+                       (const T*)h->Winv.p);
+  h->alphaT = h->AT.p;
+  h->alpha_ready = true;
   return GPX_OK;
 }
 
@@ -438,22 +456,27 @@ int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var
       launch_kbuild_cross<T>(h->cfg.kernel, (const T*)h->Qs.p, M, Mpad, (const T*)h->Xs.p, N,
                           Npad, d, h->sf2, dVT, ld, h->st);
     }
-    {
-      // mean^T (64 x Mpad) = alpha^T (64 x Npad) * K*^T
-      PhaseScope ps(h, &tm.mean);
-      launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->alphaT, ld, dVT, ld, RHS_ROWS, Mpad,
-                     Npad, 0, 1, h->st);
-      launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, k, 1.0, (T*)h->meanout.p, h->st);
-    }
     if (var) {
       {
         PhaseScope ps(h, &tm.trsm);
         solve_fwd_enqueue<T>(h, dVT, Mpad, dK, ld, Npad, h->nb_pred, dWinv);
       }
+      {  // mean^T (64 x Mpad) = z^T (64 x Npad) * V   (mu = K* K^-1 y = V^T z)
+        PhaseScope ps(h, &tm.mean);
+        launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->zT, ld, dVT, ld, RHS_ROWS, Mpad, Npad, 0, 1,
+                          h->st);
+        launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, k, 1.0, (T*)h->meanout.p, h->st);
+      }
       {
         PhaseScope ps(h, &tm.var);
         launch_var_rows<T>(dVT, ld, M, Npad, h->sf2, (T*)h->var.p, h->st);
       }
+    } else {  // mean only: K* alpha with the (cached) back-substituted alpha
+      if ((rc = ensure_alpha<T>(h))) return rc;
+      PhaseScope ps(h, &tm.mean);
+      launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->alphaT, ld, dVT, ld, RHS_ROWS, Mpad, Npad, 0, 1,
+                        h->st);
+      launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, k, 1.0, (T*)h->meanout.p, h->st);
     }
     {
       PhaseScope ps(h, &tm.d2h);
@@ -470,6 +493,7 @@ int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var
 template <typename T>
 int alpha_impl(gpx_handle* h, void* out) {
   int rc;
+  if (!h->comm && (rc = ensure_alpha<T>(h))) return rc;  // sharded handles solve alpha in fit
   if ((rc = ensure(h, h->meanout, (size_t)h->N * h->k * sizeof(T)))) return rc;
   launch_unpack_rhs<T>((const T*)h->alphaT, h->ld, h->N, h->k, 1.0, (T*)h->meanout.p, h->st);
   HIPCHK(h, hipMemcpyAsync(out, h->meanout.p, (size_t)h->N * h->k * sizeof(T), hipMemcpyDeviceToHost, h->st));
@@ -543,7 +567,7 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st2) (void)hipStreamSynchronize(h->st2);
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout, &h->G, &h->Pglob,
-                    &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv})
+                    &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT})
     release(*b);
   destroy_comm(h);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);

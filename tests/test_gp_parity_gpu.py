@@ -36,8 +36,8 @@ def test_golden_fixtures(golden_dir, name):
     assert np.max(np.abs(gp.alpha_ - z["alpha"])) <= 1e-7 * np.max(np.abs(z["alpha"]))
     assert abs(gp.log_det_ - float(z["logdet"])) <= 1e-10 * abs(float(z["logdet"]))
     assert abs(gp.log_marginal_likelihood(z["y"]) - float(z["lml"])) <= 1e-9 * abs(float(z["lml"]))
-    m_only = gp.predict(z["Xs"], return_var=False)
-    assert np.array_equal(m_only, mean)
+    m_only = gp.predict(z["Xs"], return_var=False)   # K* alpha; with variance the mean is V^T z
+    assert np.max(np.abs(m_only - mean)) <= 1e-9 * max(1.0, np.abs(mean).max())
     gp.close()
 
 

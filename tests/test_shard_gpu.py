@@ -29,7 +29,7 @@ def test_sharded_schedule_single_rank_rccl(N, M, nb, monkeypatch):
     with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0, device=0, world=1, rank=0, comm="rccl") as gp:
         mean, var = gp.fit(X, y).predict(Xs)
         check(mean, var, gp.alpha_, gp.log_det_, ref, mr, vr)
-        assert np.array_equal(gp.predict(Xs, return_var=False), mean)
+        assert np.max(np.abs(gp.predict(Xs, return_var=False) - mean)) <= 1e-9 * max(1.0, np.abs(mean).max())
 
 
 @pytest.mark.parametrize("world,kernel,nb,N", [(2, "rbf", 128, 700), (3, "matern52", 128, 700),
