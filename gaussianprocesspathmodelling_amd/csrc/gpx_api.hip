@@ -892,7 +892,12 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs) {
   double *sink = nullptr, *src = nullptr, *dst = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const int64_t count = (int64_t)1 << 28;  // 2 GiB per buffer
-  const int iters = 4096;
+  int iters = 65536;  // ~0.23 s: long enough to be past the clock ramp (a 14 ms loop read 75 TF,
+                      // the sustained rate is 77.8); GPX_MICROBENCH_ITERS overrides
+  if (const char* e = getenv("GPX_MICROBENCH_ITERS")) {
+    const long v = atol(e);
+    if (v >= 64 && v <= (1L << 20)) iters = (int)v;
+  }
   const int blocks = 256 * 8;
   float ms = 0.f;
   int rc = GPX_OK;
