@@ -10,13 +10,18 @@ M=4096 (M fixed by SURVEY.md §8) — with X, y, Xs already resident in HBM (tor
 tensors are only the containers; all arithmetic is libgpx.so).
 
 N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU.
-  --mode replicas (default): every rank runs its own replica of the workload (independent
-      GPs — e.g. one per path cluster — need no data-path collective; north_star shards
-      the Gram matrix only when N outgrows one GPU), value = points of all ranks /
+  --mode auto (default) = the graded multi-GPU path of SURVEY.md §8(e): ONE N=65536 Gram
+      matrix in row-block-cyclic shards over the ranks, panel broadcast / all-gather over
+      RCCL with one-panel look-ahead, value = (N+M) / max-over-ranks time, ``"scaling":
+      "strong"``.  The sharded run lives in a CHILD process per rank (this process touches
+      no GPU meanwhile) that writes a heartbeat and checks its posterior against the
+      single-GPU path on rank 0 (``shard_check``).  If a child fails, stalls or disagrees,
+      every rank falls back to --mode replicas and the JSON says so (``shard_fallback``).
+  --mode shard: the sharded run in-process (what the child executes).
+      ``--workload C4`` = N=262144, d=3, Matern-5/2 (needs 8 GPUs; no single-GPU check).
+  --mode replicas: every rank runs its own replica of the workload (independent GPs, e.g.
+      one per path cluster: no data-path collective), value = points of all ranks /
       max-over-ranks time, ``"scaling": "weak"``.
-  --mode shard: ONE Gram matrix in row-block-cyclic shards over the ranks, panel
-      broadcast / all-gather over RCCL, value = (N+M) / time,
-      ``"scaling": "strong"``.  ``--workload C4`` = N=262144, d=3, Matern-5/2 (needs 8 GPUs).
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline     — the dominant kernel (trailing SYRK of the blocked Cholesky, fp64 MFMA):
@@ -119,7 +124,10 @@ def main():
     ap.add_argument("--ntrain", dest="n", type=int, default=N_TRAIN, help="override N (debug only; invalidates the metric)")
     ap.add_argument("--mtest", dest="m", type=int, default=M_TEST)
     ap.add_argument("--block", type=int, default=0)
-    ap.add_argument("--mode", choices=["replicas", "shard"], default="replicas")
+    ap.add_argument("--mode", choices=["auto", "replicas", "shard"], default="auto")
+    ap.add_argument("--heartbeat", default=None, help="(internal) progress file of a supervised sharded child")
+    ap.add_argument("--stall-timeout", type=float, default=300.0,
+                    help="auto mode: seconds without child progress before the fallback")
     ap.add_argument("--workload", choices=["C3", "C4"], default="C3")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank code on one GPU (host collectives)")
@@ -127,7 +135,98 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    fallback = None
+    if args.mode == "auto":
+        if world > 1:
+            fallback = supervise_sharded_child(args)
+            if fallback is None:
+                return                      # the child printed the JSON line
+            # the children used the launcher's store; the fallback group brings up its own
+            # (rank 0 hosts it) so that no key of the dead group is ever read
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+        args.mode = "replicas"
+    run(args, fallback)
 
+
+def beat(args, what):
+    """Progress mark of a supervised child (mtime + last line are what the parent reads)."""
+    if args.heartbeat:
+        with open(args.heartbeat, "a") as f:
+            f.write(f"{time.time():.3f} {what}\n")
+
+
+def supervise_sharded_child(args):
+    """Run ``--mode shard`` in a child process (exact PID kept), watch its heartbeat file and
+    the node-wide failure flag.  Returns None when the child finished ("done" mark), else the
+    reason for the fallback.  Nothing here touches the GPU."""
+    import subprocess
+    import tempfile
+    rank = int(os.environ.get("RANK", "0"))
+    # all ranks of one launch share the launcher as parent: its pid makes the names unique per run
+    tag = f"gpx_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    tmp = tempfile.gettempdir()
+    hb = os.path.join(tmp, f"{tag}_hb{rank}")
+    flag = os.path.join(tmp, f"{tag}_failed")
+    for f in (hb,) + ((flag,) if rank == 0 else ()):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    open(hb, "w").close()
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--mode", "shard", "--heartbeat", hb]
+    child = subprocess.Popen(cmd)
+    reason = None
+    last = ""
+    while True:
+        rc = child.poll()
+        try:
+            with open(hb) as f:
+                lines = f.read().splitlines()
+            last = lines[-1].split(" ", 1)[1] if lines else ""
+            age = time.time() - os.path.getmtime(hb)
+        except OSError:
+            age = 0.0
+        if last == "done":
+            if rc is None:
+                try:
+                    child.wait(timeout=60)
+                except subprocess.TimeoutExpired:
+                    child.kill()
+            return None
+        if rc is not None:
+            reason = f"sharded child of rank {rank} exited with code {rc} after '{last}'"
+            break
+        if os.path.exists(flag):
+            reason = "sharded child of another rank failed"
+            break
+        if age > args.stall_timeout:
+            reason = f"sharded child of rank {rank} made no progress for {age:.0f} s after '{last}'"
+            break
+        time.sleep(0.5)
+    try:
+        with open(flag, "a") as f:
+            f.write(reason + "\n")
+    except OSError:
+        pass
+    if child.poll() is None:
+        child.kill()                        # exact PID of the process started above
+        child.wait()
+    print(f"[bench] {reason}; falling back to independent replicas", file=sys.stderr, flush=True)
+    time.sleep(3.0)                         # let the other ranks see the flag and reap their children
+    try:
+        with open(flag) as f:
+            reason = f.readline().strip() or reason
+    except OSError:
+        pass
+    return reason
+
+
+def run(args, fallback=None):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -135,8 +234,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    beat(args, "imports")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     if args.device is not None:
@@ -151,6 +249,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from gaussianprocesspathmodelling_amd import GP, _abi
+    beat(args, "process group")
 
     N, M = args.n, args.m
     kernel = KERNEL
@@ -168,6 +267,8 @@ def main():
                 world=world, rank=rank, comm="rccl" if args.backend == "nccl" else "host")
     else:
         gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True)
+    beat(args, "communicator + inputs")
+    inject = os.environ.get("GPX_BENCH_INJECT", "")     # rehearsal of the fallback: fail:R / hang:R
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -181,6 +282,11 @@ def main():
     def step():
         gp.fit(Xd, yd)
         mean, var = gp.predict(Xsd)
+        beat(args, "step")
+        if shard and inject == f"fail:{rank}":
+            raise RuntimeError("injected failure (GPX_BENCH_INJECT)")
+        if shard and inject == f"hang:{rank}":
+            time.sleep(1e6)
         return mean, var, gp.timings_
 
     for _ in range(args.warmup):
@@ -199,6 +305,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ok = bool(torch.isfinite(mean).all().item() and (var > 0).all().item())
+    shard_check = None
+    if shard and N <= 131072:
+        # the sharded posterior against the single-GPU path on the same inputs (rank 0's GPU)
+        verdict = [None]
+        if rank == 0:
+            with GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block) as one:
+                m1, v1 = one.fit(Xd, yd).predict(Xsd)
+            # north_star's elementwise criterion (1e-6) between two different blockings of the
+            # same factorisation, plus the error relative to the largest posterior mean
+            em = float(((mean - m1).abs() / m1.abs().clamp_min(1e-6)).max().item())
+            ev = float(((var - v1).abs() / v1.clamp_min(1e-6 * SF2)).max().item())
+            es = float(((mean - m1).abs().max() / m1.abs().max()).item())
+            del m1, v1
+            verdict[0] = {"vs": "single-GPU path, same inputs", "mean_max_rel": em, "var_max_rel": ev,
+                          "mean_err_over_max_mean": es, "tol": 1e-6,
+                          "ok": bool(em < 1e-6 and ev < 1e-6 and ok)}
+        dist.broadcast_object_list(verdict, src=0)
+        shard_check = verdict[0]
+        beat(args, "check")
+        if not shard_check["ok"]:
+            if rank == 0:
+                print(f"[bench] sharded result disagrees with the single-GPU path: {shard_check}",
+                      file=sys.stderr, flush=True)
+            sys.exit(3)
 
     if rank == 0:
         steps = max(1, args.steps)
@@ -218,11 +348,13 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: exact GP fit+predict, N={N} d={DIM} {kernel} fp64, "
                                    f"M={M}, inputs resident in HBM", "N": N, "d": DIM, "M": M,
-                       "kernel": kernel, "block": args.block or 1024,
+                       "kernel": kernel, "block": args.block or (512 if shard else 1024),
                        "parallelism": "1 gpu" if world == 1 else
                        (f"row-block-cyclic shard over {world} gpus ({'RCCL' if args.backend == 'nccl' else 'host collectives, rehearsal'})" if shard
-                        else f"{world} independent replicas")},
+                        else f"{world} independent replicas" + (" (FALLBACK: the sharded run failed)" if fallback else ""))},
             "outputs_finite": ok,
+            "shard_check": shard_check,
+            "shard_fallback": fallback,
             "phases_ms": phases,
             "roofline": {
                 "kernel": "gemm_nt_kernel<128,LOWER> (trailing SYRK of the blocked Cholesky)",
@@ -249,7 +381,12 @@ def main():
                 out["microbench"] = {"mfma_f64_loop_tflops": a.value, "stream_copy_gbs": b.value}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if world > 1:
+            sync()
         print(json.dumps(out), flush=True)
+    elif world > 1:
+        sync()
+    beat(args, "done")
     gp.close()
     if world > 1:
         dist.destroy_process_group()
