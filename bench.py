@@ -257,9 +257,9 @@ def run(args, fallback=None):
         if args.n == N_TRAIN:
             N = 262144
         kernel = "matern52"
-        if args.mode != "shard" or world < 2:
+        if not (args.mode == "shard" and world >= 2):
             raise SystemExit("--workload C4 (550 GB Gram matrix) needs --mode shard on several GPUs")
-    shard = args.mode == "shard" and world > 1
+    shard = args.mode == "shard"     # world == 1: the sharded schedule on one rank (its own overhead)
     X, y, Xs = synthetic(N, DIM, M, 12345 + (0 if shard else rank))   # replicas: own draw each
     Xd, yd, Xsd = (torch.from_numpy(a).to(dev) for a in (X, y, Xs))
     if shard:
@@ -321,7 +321,8 @@ def run(args, fallback=None):
             verdict[0] = {"vs": "single-GPU path, same inputs", "mean_max_rel": em, "var_max_rel": ev,
                           "mean_err_over_max_mean": es, "tol": 1e-6,
                           "ok": bool(em < 1e-6 and ev < 1e-6 and ok)}
-        dist.broadcast_object_list(verdict, src=0)
+        if world > 1:
+            dist.broadcast_object_list(verdict, src=0)
         shard_check = verdict[0]
         beat(args, "check")
         if not shard_check["ok"]:

@@ -75,7 +75,8 @@ struct gpx_handle {
   void* alphaT = nullptr;  // alpha^T (64 x ld): AT (computed on demand from z^T) or YT (shard)
   bool alpha_ready = false;
   DevBuf AT;
-  int nb_shard = 512;  // distribution block = panel width of the sharded factorisation
+  int nb_shard = 512;  // distribution block = panel width of the sharded factorisation (chosen per fit)
+  int nb_shard_env = 0;  // GPX_NB_SHARD override (0: choose from N and the number of ranks)
   int64_t nloc = 0, ldy = 0;
   DevBuf G, Pglob, Dbuf, Sbuf, YTloc, Cneg, Sv;
   // event pool
@@ -543,8 +544,8 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
   if (!h) return fail(nullptr, GPX_E_NOMEM, "gpx_create: out of host memory");
   h->cfg = *cfg;
   h->nb = nb;
-  if (const char* e = getenv("GPX_NB_SHARD")) h->nb_shard = atoi(e);
-  if (h->nb_shard < 128 || h->nb_shard > 2048 || h->nb_shard % 128 != 0) h->nb_shard = 512;
+  if (const char* e = getenv("GPX_NB_SHARD")) h->nb_shard_env = atoi(e);
+  if (h->nb_shard_env < 128 || h->nb_shard_env > 2048 || h->nb_shard_env % 128 != 0) h->nb_shard_env = 0;
   if (const char* e = getenv("GPX_NB_SOLVE")) h->nb_solve = atoi(e);
   if (const char* e = getenv("GPX_NB_PRED")) h->nb_pred = atoi(e);
   int prio_lo = 0, prio_hi = 0;

@@ -48,7 +48,10 @@ def main():
         vt.allreduce(None, ar2.ctypes.data, 1, 0)      # sum
         res = dict(bcast=a, allgather=g, reduce=r_out, armin=ar, arsum=ar2, err=str(hc.last_error))
     elif mode == "gpu":
-        os.environ["GPX_NB_SHARD"] = str(nb)
+        if nb > 0:
+            os.environ["GPX_NB_SHARD"] = str(nb)
+        else:                                   # 0: let the library choose from N and world
+            os.environ.pop("GPX_NB_SHARD", None)
         from gaussianprocesspathmodelling_amd import GP
         with GP(kernel, ls, sf2, sn2, jitter=0.0, device=0, world=world, rank=rank, comm="host") as gp:
             gp.fit(X, y)

@@ -33,7 +33,8 @@ def test_sharded_schedule_single_rank_rccl(N, M, nb, monkeypatch):
 
 
 @pytest.mark.parametrize("world,kernel,nb,N", [(2, "rbf", 128, 700), (3, "matern52", 128, 700),
-                                                 (2, "rbf", 256, 700), (4, "rbf", 512, 3300)])
+                                                 (2, "rbf", 256, 700), (4, "rbf", 512, 3300),
+                                                 (2, "rbf", 0, 9000)])   # 0 = block height chosen by the library
 def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N):
     res = run_ranks("gpu", world, tmp_path, {"SHARD_KERNEL": kernel, "SHARD_NB": str(nb), "SHARD_N": str(N)},
                     timeout=600)
