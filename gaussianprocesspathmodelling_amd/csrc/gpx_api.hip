@@ -79,6 +79,11 @@ struct gpx_handle {
   int nb_shard_env = 0;  // GPX_NB_SHARD override (0: choose from N and the number of ranks)
   int64_t nloc = 0, ldy = 0;
   DevBuf G, Pglob, Dbuf, Sbuf, YTloc, Cneg, Sv;
+  // replicated-factor mode of the shard: every rank keeps the whole L (the panels pass through
+  // it anyway), so solves and predictions need no per-panel exchange (gpx_shard.inc)
+  bool repl = false;
+  DevBuf Lfull, GatherS, GatherR, outM, outV;
+  const void* Lfac = nullptr;  // the factor the single-GPU solves read: K (unsharded) or Lfull
   // event pool
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -329,6 +334,9 @@ int copy_out(gpx_handle* h, void* dst, const void* src, size_t bytes, int mem_ki
   return GPX_OK;
 }
 
+template <typename T>
+int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_t mem_kind);
+
 }  // namespace
 
 #include "gpx_shard.inc"
@@ -364,6 +372,8 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   if ((rc = ensure(h, h->info, 64))) return rc;
 
   T* dK = (T*)h->K.p;
+  h->Lfac = dK;
+  h->repl = false;
   T* dYT = dK + Npad * ld;  // rows [Npad, Npad + NX) of the K buffer: y^T, then z^T = (L^-1 y)^T
   h->zT = dYT;
   h->alphaT = nullptr;
@@ -421,22 +431,23 @@ int ensure_alpha(gpx_handle* h) {
   PhaseScope ps(h, &h->tm.solve);
   HIPCHK(h, hipMemcpyAsync(h->AT.p, h->zT, (size_t)RHS_ROWS * h->ld * sizeof(T), hipMemcpyDeviceToDevice,
                            h->st));
-  solve_bwd_enqueue<T>(h, (T*)h->AT.p, RHS_ROWS, (const T*)h->K.p, h->ld, h->Npad, h->nb_solve,
+  solve_bwd_enqueue<T>(h, (T*)h->AT.p, RHS_ROWS, (const T*)h->Lfac, h->ld, h->Npad, h->nb_solve,
                        (const T*)h->Winv.p);
   h->alphaT = h->AT.p;
   h->alpha_ready = true;
   return GPX_OK;
 }
 
+// K*, variance solve, mean and variance of M query points; results stay on the device in
+// h->meanout (M x k) and h->var (M).  Reads the factor through h->Lfac (whole L).
 template <typename T>
-int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var, int32_t mem_kind) {
+int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_t mem_kind) {
+  if (M <= 0) return GPX_OK;  // a rank whose slice of the query points is empty
   const int64_t N = h->N, Npad = h->Npad, ld = h->ld;
   const int d = h->d, k = h->k;
   const int64_t Mpad = round_up(M, TILE);
   const int64_t ldm = Mpad + LD_SKEW;
   gpx_timings& tm = h->tm;
-  tm.kstar = tm.mean = tm.trsm = tm.var = tm.d2h = tm.predict_total = 0;
-
   int rc;
   if ((rc = ensure(h, h->Q, (size_t)M * d * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->Qs, (size_t)Mpad * d * sizeof(T)))) return rc;
@@ -445,45 +456,52 @@ int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var
   if ((rc = ensure(h, h->meanout, (size_t)M * k * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->var, (size_t)Mpad * sizeof(T)))) return rc;
   T* dVT = (T*)h->VT.p;
-  const T* dK = (const T*)h->K.p;
+  const T* dK = (const T*)h->Lfac;
   const T* dWinv = (const T*)h->Winv.p;
   {
-    PhaseScope total(h, &tm.predict_total);
+    PhaseScope ps(h, &tm.kstar);
+    if ((rc = copy_in(h, h->Q.p, Xq, (size_t)M * d * sizeof(T), mem_kind))) return rc;
+    launch_scale_points<T>((const T*)h->Q.p, M, Mpad, d, (const double*)h->ls.p, h->n_ls,
+                        (T*)h->Qs.p, h->st);
+    launch_kbuild_cross<T>(h->cfg.kernel, (const T*)h->Qs.p, M, Mpad, (const T*)h->Xs.p, N,
+                        Npad, d, h->sf2, dVT, ld, h->st);
+  }
+  if (want_var) {
     {
-      PhaseScope ps(h, &tm.kstar);
-      if ((rc = copy_in(h, h->Q.p, Xq, (size_t)M * d * sizeof(T), mem_kind))) return rc;
-      launch_scale_points<T>((const T*)h->Q.p, M, Mpad, d, (const double*)h->ls.p, h->n_ls,
-                          (T*)h->Qs.p, h->st);
-      launch_kbuild_cross<T>(h->cfg.kernel, (const T*)h->Qs.p, M, Mpad, (const T*)h->Xs.p, N,
-                          Npad, d, h->sf2, dVT, ld, h->st);
+      PhaseScope ps(h, &tm.trsm);
+      solve_fwd_enqueue<T>(h, dVT, Mpad, dK, ld, Npad, h->nb_pred, dWinv);
     }
-    if (var) {
-      {
-        PhaseScope ps(h, &tm.trsm);
-        solve_fwd_enqueue<T>(h, dVT, Mpad, dK, ld, Npad, h->nb_pred, dWinv);
-      }
-      {  // mean^T (64 x Mpad) = z^T (64 x Npad) * V   (mu = K* K^-1 y = V^T z)
-        PhaseScope ps(h, &tm.mean);
-        launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->zT, ld, dVT, ld, RHS_ROWS, Mpad, Npad, 0, 1,
-                          h->st);
-        launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, k, 1.0, (T*)h->meanout.p, h->st);
-      }
-      {
-        PhaseScope ps(h, &tm.var);
-        launch_var_rows<T>(dVT, ld, M, Npad, h->sf2, (T*)h->var.p, h->st);
-      }
-    } else {  // mean only: K* alpha with the (cached) back-substituted alpha
-      if ((rc = ensure_alpha<T>(h))) return rc;
+    {  // mean^T (64 x Mpad) = z^T (64 x Npad) * V   (mu = K* K^-1 y = V^T z)
       PhaseScope ps(h, &tm.mean);
-      launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->alphaT, ld, dVT, ld, RHS_ROWS, Mpad, Npad, 0, 1,
+      launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->zT, ld, dVT, ld, RHS_ROWS, Mpad, Npad, 0, 1,
                         h->st);
       launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, k, 1.0, (T*)h->meanout.p, h->st);
     }
     {
-      PhaseScope ps(h, &tm.d2h);
-      if ((rc = copy_out(h, mean, h->meanout.p, (size_t)M * k * sizeof(T), mem_kind))) return rc;
-      if (var && (rc = copy_out(h, var, h->var.p, (size_t)M * sizeof(T), mem_kind))) return rc;
+      PhaseScope ps(h, &tm.var);
+      launch_var_rows<T>(dVT, ld, M, Npad, h->sf2, (T*)h->var.p, h->st);
     }
+  } else {  // mean only: K* alpha with the (cached) back-substituted alpha
+    if ((rc = ensure_alpha<T>(h))) return rc;
+    PhaseScope ps(h, &tm.mean);
+    launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->alphaT, ld, dVT, ld, RHS_ROWS, Mpad, Npad, 0, 1,
+                      h->st);
+    launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, k, 1.0, (T*)h->meanout.p, h->st);
+  }
+  return GPX_OK;
+}
+
+template <typename T>
+int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var, int32_t mem_kind) {
+  gpx_timings& tm = h->tm;
+  tm.kstar = tm.mean = tm.trsm = tm.var = tm.d2h = tm.predict_total = 0;
+  int rc;
+  {
+    PhaseScope total(h, &tm.predict_total);
+    if ((rc = predict_core<T>(h, Xq, M, var != nullptr, mem_kind))) return rc;
+    PhaseScope ps(h, &tm.d2h);
+    if ((rc = copy_out(h, mean, h->meanout.p, (size_t)M * h->k * sizeof(T), mem_kind))) return rc;
+    if (var && (rc = copy_out(h, var, h->var.p, (size_t)M * sizeof(T), mem_kind))) return rc;
   }
   HIPCHK(h, hipStreamSynchronize(h->st));
   HIPCHK(h, hipGetLastError());
@@ -494,7 +512,7 @@ int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var
 template <typename T>
 int alpha_impl(gpx_handle* h, void* out) {
   int rc;
-  if (!h->comm && (rc = ensure_alpha<T>(h))) return rc;  // sharded handles solve alpha in fit
+  if ((!h->comm || h->repl) && (rc = ensure_alpha<T>(h))) return rc;  // the distributed shard solves alpha in fit
   if ((rc = ensure(h, h->meanout, (size_t)h->N * h->k * sizeof(T)))) return rc;
   launch_unpack_rhs<T>((const T*)h->alphaT, h->ld, h->N, h->k, 1.0, (T*)h->meanout.p, h->st);
   HIPCHK(h, hipMemcpyAsync(out, h->meanout.p, (size_t)h->N * h->k * sizeof(T), hipMemcpyDeviceToHost, h->st));
@@ -568,7 +586,8 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st2) (void)hipStreamSynchronize(h->st2);
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout, &h->G, &h->Pglob,
-                    &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT})
+                    &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
+                    &h->GatherR, &h->outM, &h->outV})
     release(*b);
   destroy_comm(h);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);

@@ -20,9 +20,12 @@ def check(mean, var, alpha, logdet, ref, mr, vr, sf2=1.5):
     assert abs(logdet - ref.log_det_) <= 1e-9 * abs(ref.log_det_)
 
 
-@pytest.mark.parametrize("N,M,nb", [(1500, 130, 256), (640, 64, 128)])
-def test_sharded_schedule_single_rank_rccl(N, M, nb, monkeypatch):
+@pytest.mark.parametrize("N,M,nb,repl", [(1500, 130, 256, 0), (640, 64, 128, 0), (1500, 130, 256, 1),
+                                          (900, 1, 128, 1)])
+def test_sharded_schedule_single_rank_rccl(N, M, nb, repl, monkeypatch):
+    """repl = 0: distributed solves (the C4-sized path); 1: whole factor kept on every rank."""
     monkeypatch.setenv("GPX_NB_SHARD", str(nb))
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", str(repl))
     X, y, Xs = synthetic_problem(N, 3, M, seed=N)
     ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
     mr, vr = ref.predict(Xs)
@@ -32,12 +35,18 @@ def test_sharded_schedule_single_rank_rccl(N, M, nb, monkeypatch):
         assert np.max(np.abs(gp.predict(Xs, return_var=False) - mean)) <= 1e-9 * max(1.0, np.abs(mean).max())
 
 
-@pytest.mark.parametrize("world,kernel,nb,N", [(2, "rbf", 128, 700), (3, "matern52", 128, 700),
-                                                 (2, "rbf", 256, 700), (4, "rbf", 512, 3300),
-                                                 (2, "rbf", 0, 9000)])   # 0 = block height chosen by the library
-def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N):
-    res = run_ranks("gpu", world, tmp_path, {"SHARD_KERNEL": kernel, "SHARD_NB": str(nb), "SHARD_N": str(N)},
-                    timeout=600)
+@pytest.mark.parametrize("world,kernel,nb,N,repl", [
+    (2, "rbf", 128, 700, 0), (3, "matern52", 128, 700, 0), (2, "rbf", 256, 700, 0), (4, "rbf", 512, 3300, 0),
+    (2, "rbf", 128, 700, 1), (3, "matern52", 128, 700, 1), (4, "rbf", 512, 3300, 1),
+    (2, "rbf", 0, 9000, -1)])   # nb 0 / repl -1 = chosen by the library (replicated at this size)
+def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N, repl):
+    """Several ranks of the sharded schedule on ONE GPU through the host transport, in both
+    solve modes: distributed (broadcast / reduce per panel) and replicated factor (query
+    points split over the ranks; M = 90 leaves the last ranks an empty slice)."""
+    env = {"SHARD_KERNEL": kernel, "SHARD_NB": str(nb), "SHARD_N": str(N)}
+    if repl >= 0:
+        env["GPX_SHARD_REPLICATE"] = str(repl)
+    res = run_ranks("gpu", world, tmp_path, env, timeout=600)
     X, y, Xs = synthetic_problem(N, 3, 90, seed=77)
     ref = OracleGP(kernel, (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
     mr, vr = ref.predict(Xs)
