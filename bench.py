@@ -59,6 +59,14 @@ def synthetic(N, d, M, seed):
     return X, y, Xs
 
 
+def shard_block(N, world):
+    """Row-block height the library picks for the shard (gpx_shard.inc: >= 16 blocks per rank)."""
+    nb = 1024
+    while nb > 256 and nb * 16 * world > N:
+        nb //= 2
+    return int(os.environ.get("GPX_NB_SHARD", nb))
+
+
 def pmc_traffic():
     """HBM bytes per SYRK launch from the committed rocprofv3 PMC passes of this same command
     (separate --pmc FETCH_SIZE / WRITE_SIZE runs; KiB units; FETCH_SIZE x2 on gfx950 for the
@@ -349,7 +357,7 @@ def run(args, fallback=None):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: exact GP fit+predict, N={N} d={DIM} {kernel} fp64, "
                                    f"M={M}, inputs resident in HBM", "N": N, "d": DIM, "M": M,
-                       "kernel": kernel, "block": args.block or (512 if shard else 1024),
+                       "kernel": kernel, "block": args.block or (shard_block(N, world) if shard else 1024),
                        "parallelism": "1 gpu" if world == 1 else
                        (f"row-block-cyclic shard over {world} gpus ({'RCCL' if args.backend == 'nccl' else 'host collectives, rehearsal'})" if shard
                         else f"{world} independent replicas" + (" (FALLBACK: the sharded run failed)" if fallback else ""))},
@@ -373,6 +381,7 @@ def run(args, fallback=None):
         out["cholesky_tflops"] = (N ** 3 / 3.0) / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
         if shard:   # the sharded update has no per-launch flop bookkeeping: rate the whole factorisation
             out["roofline"].update(kernel="blocked Cholesky, all ranks (gemm_nt_kernel<128> with block-cyclic mask)",
+                                   traffic=None, traffic_source=None,
                                    achieved=out["cholesky_tflops"], peak=PEAK_FP64_MFMA_TFLOPS * world,
                                    frac=out["cholesky_tflops"] / (PEAK_FP64_MFMA_TFLOPS * world))
         if world == 1 and not args.no_microbench:
