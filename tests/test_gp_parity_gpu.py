@@ -47,6 +47,9 @@ def test_golden_fixtures(golden_dir, name):
     (129, 1, 300, "matern52", 0.4, 128),
     (1500, 3, 130, "matern52", (0.3, 0.2, 0.25), 256),
     (2500, 2, 64, "rbf", (0.3, 0.2), 512),
+    (300, 32, 50, "rbf", 2.0, 0),                  # largest supported input dimension (generic-d kernel)
+    (700, 7, 33, "matern52", (1.0, 0.8, 1.2, 0.9, 1.1, 1.0, 0.7), 0),
+    (64, 3, 4097, "rbf", 0.25, 0),                 # more query points than training points
 ])
 def test_ragged_sizes_vs_oracle(N, d, M, kernel, ls, block):
     X, y, Xs = synthetic_problem(N, d, M, seed=N + M)
@@ -81,6 +84,23 @@ def test_multi_output_and_noise_flag():
         for c in range(3):
             assert_parity(mean[:, c], var, mr[:, c], vr, 1.2)
         assert gp.alpha_.shape == (700, 3)
+
+
+def test_max_targets_share_one_factorisation():
+    """k = 64 right-hand sides (the ABI maximum) through one Cholesky factor."""
+    X, y, Xs = synthetic_problem(900, 3, 40, seed=5)
+    rng = np.random.default_rng(1)
+    Y = y[:, None] * rng.uniform(0.5, 2.0, 64)[None, :] + 0.05 * rng.standard_normal((900, 64))
+    ref = OracleGP("matern52", 0.3, 1.0, 1e-2, jitter=0.0).fit(X, Y)
+    mr, vr = ref.predict(Xs)
+    with GP("matern52", 0.3, 1.0, 1e-2, jitter=0.0) as gp:
+        mean, var = gp.fit(X, Y).predict(Xs)
+        assert mean.shape == (40, 64)
+        for c in (0, 31, 63):
+            assert_parity(mean[:, c], var, mr[:, c], vr, 1.0)
+        assert np.max(np.abs(gp.alpha_ - ref.alpha_)) <= 1e-7 * np.abs(ref.alpha_).max()
+    with pytest.raises(Exception):
+        GP("rbf", 0.3).fit(X, np.zeros((900, 65)))
 
 
 def test_refit_reuses_handle_and_permutation_invariance():

@@ -28,5 +28,23 @@ for _ in range(reps):
          "info": info.value}
     if best is None or r["syrk_tf"] > best["syrk_tf"]:
         best = r
+lib.gpx_destroy(h)
+# end-to-end fit+predict without the profile flag (look-ahead streams free-running)
+import time
+h = C.c_void_p()
+cfg = _abi.GpxConfig(kernel=0, dtype=0, device=0, block=0, rank=0, world=1, flags=0, reserved=0)
+assert lib.gpx_create(C.byref(h), C.byref(cfg)) == 0
+M = 4096
+Xs = rng.random((M, 3)); mean = np.empty(M); var = np.empty(M)
+ts = []
+for _ in range(reps + 1):
+    t0 = time.perf_counter()
+    assert lib.gpx_fit(h, C.c_void_p(X.ctypes.data), C.c_void_p(y.ctypes.data), N, 3, 1, _abi.dptr(ls), 1, 1.5, 1e-2,
+                       0.0, _abi.MEM_HOST, C.byref(info)) == 0
+    if info.value == 0:
+        assert lib.gpx_predict(h, C.c_void_p(Xs.ctypes.data), M, C.c_void_p(mean.ctypes.data),
+                               C.c_void_p(var.ctypes.data), _abi.MEM_HOST) == 0
+    ts.append((time.perf_counter() - t0) * 1e3)
+best["step_ms_min"] = round(min(ts[1:]), 1)
 print(os.path.basename(sys.argv[1]), json.dumps(best))
 lib.gpx_destroy(h)
