@@ -241,3 +241,61 @@ class GP:
         n, k = Y.shape
         return float(-0.5 * np.sum(Y * A) - 0.5 * k * self.log_det_
                      - 0.5 * n * k * np.log(2.0 * np.pi))
+
+    def optimize(self, X, y, params=("lengthscale", "variance", "noise"), bounds=(1e-4, 1e4), maxiter=40,
+                 rel_step=1e-4):
+        """Fit the hyper-parameters by maximising the log marginal likelihood (SURVEY.md §8f
+        rank 1: the natural step after ``fit``; the reference has no counterpart).
+
+        ``params`` chooses what moves ("lengthscale" moves every ARD entry); the search runs in
+        log-space with L-BFGS-B and forward-difference gradients.  Every evaluation is one
+        ``fit()`` on the GPU — the factorisation is the only O(N^3) term, an exact gradient would
+        need K^-1 itself.  Non-positive-definite trial points count as very bad, they do not
+        raise.  Leaves the model fitted at the best point found and returns scipy's result
+        (``.fun`` = minus the log marginal likelihood there)."""
+        from scipy.optimize import minimize
+        names = [p for p in ("lengthscale", "variance", "noise") if p in params]
+        if not names or len(names) != len(tuple(params)):
+            raise ValueError("params must be a non-empty subset of lengthscale / variance / noise")
+        n_ls = self.lengthscale.size
+
+        def pack():
+            v = []
+            for p in names:
+                v.extend(np.log(self.lengthscale) if p == "lengthscale" else
+                         [np.log(max(getattr(self, p), bounds[0]))])
+            return np.asarray(v, dtype=np.float64)
+
+        def unpack(v):
+            i = 0
+            for p in names:
+                if p == "lengthscale":
+                    self.lengthscale = np.exp(v[i:i + n_ls])
+                    i += n_ls
+                else:
+                    setattr(self, p, float(np.exp(v[i])))
+                    i += 1
+
+        best = {"f": np.inf, "v": pack()}
+
+        def objective(v):
+            unpack(v)
+            try:
+                self.fit(X, y)
+                f = -self.log_marginal_likelihood(y)
+            except np.linalg.LinAlgError:
+                f = 1e300
+            if not np.isfinite(f):
+                f = 1e300
+            if f < best["f"]:
+                best["f"], best["v"] = f, np.array(v, copy=True)
+            return f
+
+        v0 = pack()
+        lo, hi = np.log(bounds[0]), np.log(bounds[1])
+        res = minimize(objective, v0, method="L-BFGS-B", jac="2-point", bounds=[(lo, hi)] * v0.size,
+                       options={"maxiter": int(maxiter), "eps": float(rel_step)})
+        unpack(best["v"])
+        self.fit(X, y)
+        res.x, res.fun = best["v"], best["f"]
+        return res

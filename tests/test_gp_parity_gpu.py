@@ -169,3 +169,24 @@ def test_config_C3_n65536_properties():
         Ks = kernel_matrix(Xs[:256], X, "rbf", 0.25, sf2)
         assert np.max(np.abs(Ks @ alpha - mean[:256])) <= 1e-9 * max(1.0, np.abs(mean).max())
         print("C3 timings:", gp.timings_)
+
+
+def test_hyperparameter_optimisation_climbs_the_marginal_likelihood():
+    """§8(f) rank 1: L-BFGS-B over log-hyper-parameters, every evaluation one GPU fit.  The
+    likelihood it reports must be the oracle's at the same point, must not be below the start,
+    and must reach the neighbourhood of the generating parameters' likelihood."""
+    rng = np.random.default_rng(3)
+    N = 500
+    X = rng.uniform(0, 1, (N, 2))
+    Ktrue = kernel_matrix(X, X, "rbf", (0.2, 0.4), 1.3) + 0.02 * np.eye(N)
+    y = np.linalg.cholesky(Ktrue) @ rng.standard_normal(N)
+    truth = OracleGP("rbf", (0.2, 0.4), 1.3, 0.02, jitter=0.0).fit(X, y).log_marginal_likelihood()
+    with GP("rbf", (1.0, 1.0), 0.5, 0.2, jitter=0.0) as gp:
+        start = gp.fit(X, y).log_marginal_likelihood(y)
+        res = gp.optimize(X, y, maxiter=60)
+        final = gp.log_marginal_likelihood(y)
+        assert abs(final + res.fun) <= 1e-9 * abs(final)
+        assert final >= start and final >= truth - 3.0          # within a few nats of the truth
+        ref = OracleGP("rbf", gp.lengthscale, gp.variance, gp.noise, jitter=0.0).fit(X, y)
+        assert abs(final - ref.log_marginal_likelihood()) <= 1e-8 * abs(final)
+        assert 0.1 < gp.lengthscale[0] < 0.4 and 0.2 < gp.lengthscale[1] < 0.8
