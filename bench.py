@@ -249,9 +249,13 @@ def run(args, fallback=None):
         local = args.device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # Sharded runs: torch.distributed is only the control plane (RCCL unique id, barriers, the
+    # max-over-ranks time) and runs on gloo; the data path is libgpx.so calling RCCL itself.
+    # Replicas have no data path between ranks: their barriers go over torch's RCCL backend.
+    ctrl_nccl = args.backend == "nccl" and args.mode != "shard"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if ctrl_nccl:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -281,7 +285,7 @@ def run(args, fallback=None):
     def sync():
         torch.cuda.synchronize(dev)
         if world > 1:
-            if args.backend == "nccl":
+            if ctrl_nccl:
                 dist.barrier(device_ids=[local])
             else:
                 dist.barrier()
@@ -309,7 +313,7 @@ def run(args, fallback=None):
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if ctrl_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ok = bool(torch.isfinite(mean).all().item() and (var > 0).all().item())
