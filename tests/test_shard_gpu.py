@@ -21,7 +21,7 @@ def check(mean, var, alpha, logdet, ref, mr, vr, sf2=1.5):
 
 
 @pytest.mark.parametrize("N,M,nb,repl", [(1500, 130, 256, 0), (640, 64, 128, 0), (1500, 130, 256, 1),
-                                          (900, 1, 128, 1)])
+                                          (900, 1, 128, 1), (100, 5, 128, 0), (100, 5, 128, 1)])  # last two: ONE block
 def test_sharded_schedule_single_rank_rccl(N, M, nb, repl, monkeypatch):
     """repl = 0: distributed solves (the C4-sized path); 1: whole factor kept on every rank."""
     monkeypatch.setenv("GPX_NB_SHARD", str(nb))
@@ -38,6 +38,8 @@ def test_sharded_schedule_single_rank_rccl(N, M, nb, repl, monkeypatch):
 @pytest.mark.parametrize("world,kernel,nb,N,repl", [
     (2, "rbf", 128, 700, 0), (3, "matern52", 128, 700, 0), (2, "rbf", 256, 700, 0), (4, "rbf", 512, 3300, 0),
     (2, "rbf", 128, 700, 1), (3, "matern52", 128, 700, 1), (4, "rbf", 512, 3300, 1),
+    (2, "rbf", 128, 100, 0), (2, "rbf", 128, 100, 1),      # one block: rank 1 owns no rows at all
+    (3, "rbf", 128, 250, 0), (3, "rbf", 128, 250, 1),      # two blocks on three ranks
     (2, "rbf", 0, 9000, -1)])   # nb 0 / repl -1 = chosen by the library (replicated at this size)
 def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N, repl):
     """Several ranks of the sharded schedule on ONE GPU through the host transport, in both
