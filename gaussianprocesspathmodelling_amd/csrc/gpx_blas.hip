@@ -346,8 +346,8 @@ __device__ __forceinline__ void tri_coords(int64_t t, int& ti, int& tj) {
 // Logical tile order: 8x8 super-tiles (64 tiles = what one XCD runs concurrently at 2
 // workgroups per CU), so the tiles in flight on an XCD share 8 A row-slices and 8 B
 // row-slices through its L2 instead of re-fetching the panel per tile.
-//   TRI : super-tiles enumerate the lower triangle of the super-tile grid (m == n);
-//         slots above the diagonal exit at once (<= 3 % of the grid at T >= 64).
+//   TRI : the lower triangle (m == n) without holes: the full super-tiles below the
+//         diagonal, then the valid tiles of the diagonal super-tiles (see tile_coords).
 //   !TRI: rectangular super-tile grid (sh x 64/sh tiles each); mask_lower 1 also drops
 //         tiles with tj > ti (look-ahead strip of the SYRK), 2 applies the block-cyclic
 //         row map of the sharded trailing update.
@@ -362,11 +362,28 @@ __device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, int tiles_
   const int64_t st = lin >> 6;
   const int inner = (int)(lin & 63);
   if (TRI) {
-    int sr, sc;
-    tri_coords(st, sr, sc);
-    ti = sr * 8 + (inner >> 3);
-    tj = sc * 8 + (inner & 7);
-    return ti < tiles_m && tj <= ti && tj < tiles_n;  // tiles_n < tiles_m: bordered extra rows
+    // No holes: first every FULL super-tile strictly below the diagonal of the super-tile
+    // grid, then the 36 valid tiles of each diagonal super-tile packed back to back.  With
+    // the diagonal super-tiles enumerated in place, their 28 masked slots exited at once and
+    // ran one whole tile ahead of their neighbours, which scrambles the k-phase the tiles
+    // of a super-tile need to share their panel rows through L2.
+    const int S = (tiles_m + 7) >> 3;
+    const int64_t full = (int64_t)S * (S - 1) / 2 * 64;
+    if (lin < full) {
+      int i, j;
+      tri_coords(st, i, j);  // strictly lower: super-row i + 1, super-column j
+      ti = (i + 1) * 8 + (inner >> 3);
+      tj = j * 8 + (inner & 7);
+    } else {
+      const int64_t id2 = lin - full;
+      const int k = (int)(id2 / 36), e = (int)(id2 - (int64_t)k * 36);
+      int r = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      if (r * (r + 1) / 2 > e) --r;
+      if ((r + 1) * (r + 2) / 2 <= e) ++r;
+      ti = k * 8 + r;
+      tj = k * 8 + (e - r * (r + 1) / 2);
+    }
+    return ti < tiles_m && tj < tiles_n;  // ragged edge only (tiles_m not a multiple of 8)
   } else {
     const int sw = 64 / sh;  // sh in {1, 8}
     const int sn = (tiles_n + sw - 1) / sw;
@@ -706,7 +723,7 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
   dim3 block(256);
   if (lower == 1) {  // full lower triangle, triangular super-tile enumeration
     const int64_t ts = (tm + 7) / 8;
-    dim3 grid((unsigned)(ts * (ts + 1) / 2 * 64));
+    dim3 grid((unsigned)(ts * (ts - 1) / 2 * 64 + ts * 36));  // tile_coords<TRI>: no masked slots
     if (mode == 0)
       hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
     else
