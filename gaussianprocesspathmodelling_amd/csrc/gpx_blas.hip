@@ -420,33 +420,57 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 // Local tile row ti stands for global tile row lim(ti) = ((ti/tpb)*P + c)*tpb + ti%tpb of the
 // trailing matrix and owns the tiles tj <= lim(ti): a staircase.  Launching the bounding
 // rectangle leaves half of the XCD chunks empty (measured: 37.7 TF where the triangular
-// enumeration of the unsharded path gets 68), so the host counts the 8x8 super-tiles each
-// super-row needs (pre[]: exclusive prefix sums, passed by value) and a workgroup finds its
-// super-row by binary search: only super-tiles that touch the staircase are launched and
-// consecutive ids stay 8x8 neighbours for the L2.
+// enumeration of the unsharded path gets 68), so the host counts, per super-row of 8 tile rows, the
+// 8x8 super-tiles all its rows own completely plus its ragged remainder in single tiles
+// (pre[]: exclusive prefix sums of tile slots, passed by value) and a workgroup finds its
+// super-row by binary search: exactly the owned tiles are launched — no masked slot that
+// would exit at once and scramble the k-phase of its neighbours (cf. tile_coords<TRI>) —
+// and the full part stays 8x8 for the L2.
 constexpr int STAIR_MAX = 256;
 struct StairMap {
   int nsr;
   unsigned pre[STAIR_MAX + 1];
 };
 
+// columns owned by local tile row ti (clipped to the launch): tj <= stair_lim
+__host__ __device__ __forceinline__ int stair_lim(const BcMask& bc, int ti, int tiles_n) {
+  const int lim = ((ti / bc.tpb) * bc.P + bc.c) * bc.tpb + ti % bc.tpb;
+  return lim < tiles_n - 1 ? lim : tiles_n - 1;
+}
+
 template <typename T, int BT, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_stair_kernel(
     T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
     int64_t ldb, int tiles_m, int tiles_n, BcMask bc, int K, StairMap map) {
   __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
-  const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
-  const unsigned st = (unsigned)__builtin_amdgcn_readfirstlane((int)(lin >> 6));
-  const int inner = (int)(lin & 63);
+  const unsigned lin = (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_chunk_id(blockIdx.x, gridDim.x));
   int lo = 0, hi = map.nsr;
-  while (hi - lo > 1) {  // largest super-row with pre[] <= st
+  while (hi - lo > 1) {  // largest super-row with pre[] <= lin (pre[] counts tile slots)
     const int mid = (lo + hi) >> 1;
-    if (map.pre[mid] <= st) lo = mid; else hi = mid;
+    if (map.pre[mid] <= lin) lo = mid; else hi = mid;
   }
-  const int ti = lo * 8 + (inner >> 3);
-  const int tj = (int)(st - map.pre[lo]) * 8 + (inner & 7);
-  if (ti >= tiles_m || tj >= tiles_n) return;
-  if (tj > ((ti / bc.tpb) * bc.P + bc.c) * bc.tpb + ti % bc.tpb) return;
+  // super-row lo: the super-columns every one of its 8 rows owns completely come first
+  // (8x8 super-tiles, 64 slots each), then the ragged remainder row by row — no masked slot
+  const int row0 = lo * 8;
+  const int nfull = (stair_lim(bc, row0, tiles_n) + 1) >> 3;
+  unsigned off = lin - map.pre[lo];
+  int ti, tj;
+  if (off < (unsigned)nfull * 64u) {
+    ti = row0 + (int)((off & 63u) >> 3);
+    tj = (int)(off >> 6) * 8 + (int)(off & 7u);
+  } else {
+    off -= (unsigned)nfull * 64u;
+    int r = 0;
+    for (; r < 8; ++r) {
+      const int row = row0 + r;
+      const unsigned extra = row < tiles_m ? (unsigned)(stair_lim(bc, row, tiles_n) + 1 - nfull * 8) : 0u;
+      if (off < extra) break;
+      off -= extra;
+    }
+    ti = row0 + r;
+    tj = nfull * 8 + (int)off;
+  }
+  if (ti >= tiles_m || tj >= tiles_n) return;  // ragged bottom edge only
   typename Num<T>::v4 acc[BT / 32][BT / 32];
   zero_acc(acc);
   gemm_tile_g<T, BT, BT>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc,
@@ -784,15 +808,17 @@ void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, i
   }
   StairMap map;
   map.nsr = (int)nsr;
-  unsigned total = 0;
+  unsigned total = 0;  // tile slots, exactly the owned tiles (plus the ragged bottom edge of full super-tiles)
   for (int64_t sr = 0; sr < nsr; ++sr) {
     map.pre[sr] = total;
-    const int64_t tl = std::min<int64_t>(8 * sr + 7, tm - 1);  // the staircase is monotone
-    const int64_t lim = ((tl / bc_tpb) * bc_P + bc_c) * bc_tpb + tl % bc_tpb;
-    total += (unsigned)(std::min<int64_t>(lim, tn - 1) / 8 + 1);
+    const int row0 = (int)(8 * sr);
+    const int nfull = (stair_lim(bc, row0, (int)tn) + 1) >> 3;
+    total += (unsigned)nfull * 64u;
+    for (int r = 0; r < 8 && row0 + r < tm; ++r)
+      total += (unsigned)(stair_lim(bc, row0 + r, (int)tn) + 1 - nfull * 8);
   }
   map.pre[nsr] = total;
-  hipLaunchKernelGGL((gemm_nt_stair_kernel<T, 128, 0>), dim3(total * 64u), dim3(256), 0, st, C, ldc, A, lda,
+  hipLaunchKernelGGL((gemm_nt_stair_kernel<T, 128, 0>), dim3(total), dim3(256), 0, st, C, ldc, A, lda,
                      B, ldb, (int)tm, (int)tn, bc, (int)k, map);
 }
 
