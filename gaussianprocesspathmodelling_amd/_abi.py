@@ -71,6 +71,8 @@ SIGNATURES = {
     "gpx_potrf": (C.c_int, [_PD, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
     "gpx_trsm": (C.c_int, [_PD, C.c_int64, _PD, C.c_int64]),
     "gpx_gemm_nt": (C.c_int, [_PD, C.c_int64, C.c_int64, _PD, _PD, C.c_int64, C.c_int32]),
+    "gpx_debug_tile_map": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                     C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]),
     "gpx_mfma_probe": (C.c_int, [_PD, _PD, _PD]),
     "gpx_mfma_probe_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpx_microbench": (C.c_int, [_PD, _PD]),

@@ -330,12 +330,12 @@ __device__ __forceinline__ void store_tile(T* C, int64_t ldc,
 
 // blocks are dealt round-robin over the 8 XCDs; give each XCD one contiguous chunk of
 // the logical tile order so that neighbouring tiles share an L2 (speed only).
-__device__ __forceinline__ int64_t xcd_chunk_id(int64_t bid, int64_t nblk) {
+__host__ __device__ __forceinline__ int64_t xcd_chunk_id(int64_t bid, int64_t nblk) {
   const int64_t q = nblk >> 3, r = nblk & 7, x = bid & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-__device__ __forceinline__ void tri_coords(int64_t t, int& ti, int& tj) {
+__host__ __device__ __forceinline__ void tri_coords(int64_t t, int& ti, int& tj) {
   int64_t i = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while (i * (i + 1) / 2 > t) --i;
   while ((i + 1) * (i + 2) / 2 <= t) ++i;
@@ -357,7 +357,7 @@ struct BcMask {   // block-cyclic row map of the sharded trailing update (P == 0
 };
 
 template <bool TRI>
-__device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, int tiles_n, int sh,
+__host__ __device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, int tiles_n, int sh,
                                             int mask_lower, const BcMask& bc, int& ti, int& tj) {
   const int64_t st = lin >> 6;
   const int inner = (int)(lin & 63);
@@ -438,12 +438,10 @@ __host__ __device__ __forceinline__ int stair_lim(const BcMask& bc, int ti, int 
   return lim < tiles_n - 1 ? lim : tiles_n - 1;
 }
 
-template <typename T, int BT, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_stair_kernel(
-    T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
-    int64_t ldb, int tiles_m, int tiles_n, BcMask bc, int K, StairMap map) {
-  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
-  const unsigned lin = (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_chunk_id(blockIdx.x, gridDim.x));
+// tile slot lin of the staircase launch -> (ti, tj); pure index arithmetic, also run on the
+// host by gpx_debug_tile_map (tests/test_tile_maps.py checks every owned tile appears once)
+__host__ __device__ __forceinline__ void stair_coords(const StairMap& map, const BcMask& bc, unsigned lin,
+                                                      int tiles_m, int tiles_n, int& ti, int& tj) {
   int lo = 0, hi = map.nsr;
   while (hi - lo > 1) {  // largest super-row with pre[] <= lin (pre[] counts tile slots)
     const int mid = (lo + hi) >> 1;
@@ -454,7 +452,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stair_kernel(
   const int row0 = lo * 8;
   const int nfull = (stair_lim(bc, row0, tiles_n) + 1) >> 3;
   unsigned off = lin - map.pre[lo];
-  int ti, tj;
   if (off < (unsigned)nfull * 64u) {
     ti = row0 + (int)((off & 63u) >> 3);
     tj = (int)(off >> 6) * 8 + (int)(off & 7u);
@@ -470,6 +467,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stair_kernel(
     ti = row0 + r;
     tj = nfull * 8 + (int)off;
   }
+}
+
+// host: prefix sums of tile slots per super-row; returns the grid size
+inline unsigned build_stair_map(const BcMask& bc, int64_t tm, int64_t tn, StairMap& map) {
+  const int64_t nsr = (tm + 7) / 8;
+  map.nsr = (int)nsr;
+  unsigned total = 0;  // exactly the owned tiles (plus the ragged bottom edge of full super-tiles)
+  for (int64_t sr = 0; sr < nsr; ++sr) {
+    map.pre[sr] = total;
+    const int row0 = (int)(8 * sr);
+    const int nfull = (stair_lim(bc, row0, (int)tn) + 1) >> 3;
+    total += (unsigned)nfull * 64u;
+    for (int r = 0; r < 8 && row0 + r < tm; ++r)
+      total += (unsigned)(stair_lim(bc, row0 + r, (int)tn) + 1 - nfull * 8);
+  }
+  map.pre[nsr] = total;
+  return total;
+}
+
+template <typename T, int BT, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_stair_kernel(
+    T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+    int64_t ldb, int tiles_m, int tiles_n, BcMask bc, int K, StairMap map) {
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
+  const unsigned lin = (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_chunk_id(blockIdx.x, gridDim.x));
+  int ti, tj;
+  stair_coords(map, bc, lin, tiles_m, tiles_n, ti, tj);
   if (ti >= tiles_m || tj >= tiles_n) return;  // ragged bottom edge only
   typename Num<T>::v4 acc[BT / 32][BT / 32];
   zero_acc(acc);
@@ -807,17 +831,7 @@ void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, i
     return;
   }
   StairMap map;
-  map.nsr = (int)nsr;
-  unsigned total = 0;  // tile slots, exactly the owned tiles (plus the ragged bottom edge of full super-tiles)
-  for (int64_t sr = 0; sr < nsr; ++sr) {
-    map.pre[sr] = total;
-    const int row0 = (int)(8 * sr);
-    const int nfull = (stair_lim(bc, row0, (int)tn) + 1) >> 3;
-    total += (unsigned)nfull * 64u;
-    for (int r = 0; r < 8 && row0 + r < tm; ++r)
-      total += (unsigned)(stair_lim(bc, row0 + r, (int)tn) + 1 - nfull * 8);
-  }
-  map.pre[nsr] = total;
+  const unsigned total = build_stair_map(bc, tm, tn, map);
   hipLaunchKernelGGL((gemm_nt_stair_kernel<T, 128, 0>), dim3(total), dim3(256), 0, st, C, ldc, A, lda,
                      B, ldb, (int)tm, (int)tn, bc, (int)k, map);
 }
@@ -831,6 +845,43 @@ void launch_gemm_nn(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int6
   const int64_t nblk = rect_grid(tm, tn, sh);
   hipLaunchKernelGGL(gemm_nn_kernel<T>, dim3((unsigned)nblk), dim3(256), 0, st, C, ldc, A, lda, B, ldb,
                      (int)tm, (int)tn, sh, (int)k);
+}
+
+// Host-side replay of the two hole-free tile maps, exactly as the kernels index them
+// (xcd_chunk_id over the launched grid, then tile_coords<TRI> / stair_coords).  kind 0: lower
+// triangle of a tm x tm tile grid; kind 1: block-cyclic staircase (bc) of a tm x tn grid.
+// Writes (ti, tj) pairs of the valid slots; returns their number, or -1 if cap is too small
+// or the staircase needs more than STAIR_MAX super-rows.
+int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, int bc_c, int32_t* out,
+                       int64_t cap) {
+  int64_t n = 0;
+  if (kind == 0) {
+    const int64_t ts = (tm + 7) / 8;
+    const int64_t grid = ts * (ts - 1) / 2 * 64 + ts * 36;
+    for (int64_t b = 0; b < grid; ++b) {
+      int ti, tj;
+      if (!tile_coords<true>(xcd_chunk_id(b, grid), (int)tm, (int)tm, 8, 0, BcMask{0, 1, 0}, ti, tj)) continue;
+      if (n >= cap) return -1;
+      out[2 * n] = ti;
+      out[2 * n + 1] = tj;
+      ++n;
+    }
+  } else {
+    const BcMask bc{bc_P, bc_tpb, bc_c};
+    if ((tm + 7) / 8 > STAIR_MAX) return -1;
+    StairMap map;
+    const unsigned grid = build_stair_map(bc, tm, tn, map);
+    for (unsigned b = 0; b < grid; ++b) {
+      int ti, tj;
+      stair_coords(map, bc, (unsigned)xcd_chunk_id(b, grid), (int)tm, (int)tn, ti, tj);
+      if (ti >= tm || tj >= tn) continue;
+      if (n >= cap) return -1;
+      out[2 * n] = ti;
+      out[2 * n + 1] = tj;
+      ++n;
+    }
+  }
+  return n;
 }
 
 #define GPX_INSTANTIATE_BLAS(T)                                                                         \

@@ -79,6 +79,8 @@ void launch_logdet(const T* A, int64_t lda, int64_t n, double* out, hipStream_t 
 void launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st);
 void launch_mfma_probe_f32(const float* A, const float* B, float* D, hipStream_t st);
 void launch_mfma_loop(double* sink, int iters, int blocks, hipStream_t st);
+int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, int bc_c, int32_t* out,
+                       int64_t cap);
 void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st);
 
 // ---- path distance (gpx_paths.hip) -----------------------------------------------------------

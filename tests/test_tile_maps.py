@@ -1,0 +1,80 @@
+"""CPU: the hole-free tile maps of the trailing-update kernels, replayed on the host through
+gpx_debug_tile_map (same index functions the kernels call, same XCD chunking): every owned
+tile is enumerated exactly once and nothing else is.  No GPU needed — pure index arithmetic."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def tile_map(gpx, kind, tm, tn=0, P=1, tpb=1, c=0):
+    cap = int(tm) * int(max(tn, tm)) + 64
+    out = np.empty((cap, 2), dtype=np.int32)
+    count = C.c_int64(0)
+    rc = gpx.gpx_debug_tile_map(kind, tm, tn, P, tpb, c, out.ctypes.data_as(C.POINTER(C.c_int32)), cap,
+                                C.byref(count))
+    assert rc == 0
+    return out[:count.value]
+
+
+@pytest.mark.parametrize("tm", [1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 100, 256, 504])
+def test_triangle_map_is_a_bijection(gpx, tm):
+    pairs = tile_map(gpx, 0, tm)
+    want = {(i, j) for i in range(tm) for j in range(i + 1)}
+    got = [tuple(p) for p in pairs.tolist()]
+    assert len(got) == len(set(got)) == len(want) and set(got) == want
+
+
+def staircase(tm, tn, P, tpb, c):
+    return {(ti, tj) for ti in range(tm)
+            for tj in range(min(((ti // tpb) * P + c) * tpb + ti % tpb, tn - 1) + 1)}
+
+
+@pytest.mark.parametrize("tm,tn,P,tpb,c", [
+    (8, 8, 1, 8, 0),            # one rank, nb = 1024: the plain triangle
+    (64, 64, 1, 8, 0),
+    (60, 500, 8, 4, 3),         # P = 8, nb = 512: ragged part spans several super-columns
+    (32, 256, 8, 4, 0),
+    (33, 129, 4, 2, 1),         # tile rows not a multiple of 8
+    (16, 4, 2, 4, 0),           # the STRIP: only one block column wide
+    (5, 3, 3, 1, 2),
+    (256, 2040, 8, 8, 7),
+])
+def test_staircase_map_is_a_bijection(gpx, tm, tn, P, tpb, c):
+    pairs = tile_map(gpx, 1, tm, tn, P, tpb, c)
+    want = staircase(tm, tn, P, tpb, c)
+    got = [tuple(p) for p in pairs.tolist()]
+    assert len(got) == len(set(got)) == len(want) and set(got) == want
+
+
+def test_staircase_map_random(gpx):
+    rng = np.random.default_rng(5)
+    for _ in range(60):
+        tpb = int(rng.choice([1, 2, 4, 8, 16]))
+        P = int(rng.integers(1, 9))
+        nloc_blocks = int(rng.integers(1, 7))
+        tm = nloc_blocks * tpb
+        c = int(rng.integers(0, P + 1))
+        full = ((nloc_blocks - 1) * P + c + 1) * tpb          # width that holds the whole staircase
+        tn = int(rng.integers(1, full + 1))
+        pairs = tile_map(gpx, 1, tm, tn, P, tpb, c)
+        want = staircase(tm, tn, P, tpb, c)
+        got = [tuple(p) for p in pairs.tolist()]
+        assert len(got) == len(set(got)) == len(want) and set(got) == want, (tm, tn, P, tpb, c)
+
+
+def test_first_super_tiles_are_compact(gpx):
+    """The L2 argument of DESIGN.md §3.1: 64 consecutive launch slots of one XCD chunk touch at
+    most 16 panel row blocks (8 rows + 8 columns of tiles) while super-tiles are full."""
+    tm = 128
+    pairs = tile_map(gpx, 0, tm)
+    total = len(pairs)                       # no masked slots when tm is a multiple of 8
+    chunk = total // 8                       # logical ids of XCD x: [x*chunk, (x+1)*chunk)
+    logical = np.empty((total, 2), dtype=np.int64)
+    q, r = divmod(total, 8)
+    for b in range(total):                   # invert the XCD chunking: launch order -> logical order
+        x = b & 7
+        lin = (x * (q + 1) if x < r else r * (q + 1) + (x - r) * q) + (b >> 3)
+        logical[lin] = pairs[b]
+    first = logical[:64]
+    assert len(set(first[:, 0])) == 8 and len(set(first[:, 1])) == 8
