@@ -519,11 +519,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(T* __restrict__ C, int6
 }
 
 // ---- POTF2 of one 64x64 block + explicit inverse -------------------------------------
-// One workgroup, everything in LDS.  Factorisation in 16 steps of 4 columns:
-//   phase A  every thread factors the 4x4 diagonal block redundantly in registers
-//            (rsqrt-based, no divisions); thread i < 64 solves its row of the 4-column
-//            panel and drops it in PB[64][4];
-//   phase B  the rank-4 trailing update C -= PB PB^T is ONE 16x16x4 MFMA per 16x16 tile
+// One workgroup, everything in LDS.  Factorisation in 8 steps of PW = 8 columns (4-column
+// steps: 18.9 us of the kernel's 28 in 16 x two barriers + LDS round trips):
+//   phase A  every thread factors the 8x8 diagonal block redundantly in registers
+//            (rsqrt-based, no divisions); thread i < 64 solves its row of the 8-column
+//            panel and drops it in PB[64][8];
+//   phase B  the rank-8 trailing update C -= PB PB^T is TWO 16x16x4 MFMAs per 16x16 tile
 //            (<= 10 lower tiles over 4 waves); columns already final are masked through a
 //            zero B operand and predicated stores.
 // Inverse W = L^-1 by recursive blocking: four 16x16 diagonal inverses (one column per
@@ -536,6 +537,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(T* __restrict__ C, int6
 // NaN propagate (LAPACK potrf info convention).
 constexpr int PLD = 66;
 constexpr int TLD = 34;
+constexpr int PW = 8;  // columns per factorisation step (a multiple of 4: one MFMA per 4)
 
 template <typename T>
 __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_t lda,
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
   using v4 = typename Num<T>::v4;
   __shared__ __attribute__((aligned(16))) T Wk[64 * PLD];  // working matrix -> L (lower)
   __shared__ __attribute__((aligned(16))) T Wi[64 * PLD];  // inverse
-  __shared__ __attribute__((aligned(16))) T PB[64 * 4];    // current 4-column panel
+  __shared__ __attribute__((aligned(16))) T PB[64 * PW];   // current PW-column panel
   __shared__ __attribute__((aligned(16))) T Tm[32 * TLD];  // product scratch
   __shared__ T Rinv[64];                                    // 1 / L[i][i]
   __builtin_amdgcn_s_setprio(3);
@@ -559,69 +561,75 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
   }
   __syncthreads();
 
-  for (int j = 0; j < 64; j += 4) {
-    // ---- phase A: 4x4 diagonal factor (redundant per thread) + this thread's panel row
-    const T* D = Wk + j * PLD + j;
-    const T a00 = D[0];
-    const T a10 = D[PLD], a11 = D[PLD + 1];
-    const T a20 = D[2 * PLD], a21 = D[2 * PLD + 1], a22 = D[2 * PLD + 2];
-    const T a30 = D[3 * PLD], a31 = D[3 * PLD + 1], a32 = D[3 * PLD + 2], a33 = D[3 * PLD + 3];
-    const T rs0 = Num<T>::rsq(a00);
-    const T l10 = a10 * rs0, l20 = a20 * rs0, l30 = a30 * rs0;
-    const T b11 = a11 - l10 * l10;
-    const T rs1 = Num<T>::rsq(b11);
-    const T l21 = (a21 - l20 * l10) * rs1, l31 = (a31 - l30 * l10) * rs1;
-    const T b22 = a22 - l20 * l20 - l21 * l21;
-    const T rs2 = Num<T>::rsq(b22);
-    const T l32 = (a32 - l30 * l20 - l31 * l21) * rs2;
-    const T b33 = a33 - l30 * l30 - l31 * l31 - l32 * l32;
-    const T rs3 = Num<T>::rsq(b33);
+  for (int j = 0; j < 64; j += PW) {
+    // ---- phase A: PW x PW diagonal factor (redundant per thread, right-looking in
+    //      registers) + this thread's panel row
+    T a[PW][PW], rs[PW];
+    bool okp[PW];
+#pragma unroll
+    for (int c = 0; c < PW; ++c)
+#pragma unroll
+      for (int r = c; r < PW; ++r) a[r][c] = Wk[(j + r) * PLD + j + c];
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+      okp[k] = a[k][k] > zero;
+      rs[k] = Num<T>::rsq(a[k][k]);
+#pragma unroll
+      for (int r = k + 1; r < PW; ++r) a[r][k] *= rs[k];
+#pragma unroll
+      for (int c = k + 1; c < PW; ++c)
+#pragma unroll
+        for (int r = c; r < PW; ++r) a[r][c] -= a[r][k] * a[c][k];
+    }
     if (tid == 0) {
-      const int bad = !(a00 > zero) ? 1 : !(b11 > zero) ? 2 : !(b22 > zero) ? 3 : !(b33 > zero) ? 4 : 0;
+      int bad = 0;
+#pragma unroll
+      for (int k = PW - 1; k >= 0; --k)
+        if (!okp[k]) bad = k + 1;  // first non-positive (or NaN) pivot of this step
       if (bad) atomicMin(info, (int)(gidx0 + j + bad));
-      Rinv[j] = rs0;
-      Rinv[j + 1] = rs1;
-      Rinv[j + 2] = rs2;
-      Rinv[j + 3] = rs3;
+#pragma unroll
+      for (int k = 0; k < PW; ++k) Rinv[j + k] = rs[k];
     }
     if (tid < 64) {
       const int i = tid;
-      T x0 = zero, x1 = zero, x2 = zero, x3 = zero;
+      T x[PW];
+#pragma unroll
+      for (int k = 0; k < PW; ++k) x[k] = zero;
       if (i >= j) {
         const T* row = Wk + i * PLD + j;
-        x0 = row[0] * rs0;
-        x1 = (row[1] - x0 * l10) * rs1;
-        x2 = (row[2] - x0 * l20 - x1 * l21) * rs2;
-        x3 = (row[3] - x0 * l30 - x1 * l31 - x2 * l32) * rs3;
         const int c = i - j;  // rows of the diagonal block: strictly-upper part is zero
-        if (c < 1) x1 = zero;
-        if (c < 2) x2 = zero;
-        if (c < 3) x3 = zero;
+#pragma unroll
+        for (int k = 0; k < PW; ++k) {
+          T v = row[k];
+#pragma unroll
+          for (int m = 0; m < k; ++m) v -= x[m] * a[k][m];
+          x[k] = (c < k) ? zero : v * rs[k];
+        }
       }
-      PB[i * 4 + 0] = x0;
-      PB[i * 4 + 1] = x1;
-      PB[i * 4 + 2] = x2;
-      PB[i * 4 + 3] = x3;
+#pragma unroll
+      for (int k = 0; k < PW; ++k) PB[i * PW + k] = x[k];
     }
     __syncthreads();
-    // ---- phase B: commit the panel, rank-4 update of the trailing lower tiles
+    // ---- phase B: commit the panel, rank-PW update of the trailing lower tiles
     if (tid < 64 && tid >= j) {
       T* row = Wk + tid * PLD + j;
-      row[0] = PB[tid * 4 + 0];
-      row[1] = PB[tid * 4 + 1];
-      row[2] = PB[tid * 4 + 2];
-      row[3] = PB[tid * 4 + 3];
+#pragma unroll
+      for (int k = 0; k < PW; ++k) row[k] = PB[tid * PW + k];
     }
-    const int jn = j + 4;
+    const int jn = j + PW;
     const int t0 = jn >> 4;
     int idx = 0;
     for (int tr = t0; tr < 4; ++tr)
       for (int tc = t0; tc <= tr; ++tc, ++idx) {
         if ((idx & 3) != wave) continue;
         const int colg = tc * 16 + l15;
-        const T a = PB[(tr * 16 + l15) * 4 + l4];
-        const T b = (colg >= jn) ? PB[colg * 4 + l4] : zero;
-        const v4 acc = Num<T>::mfma(a, b, (v4){0, 0, 0, 0});
+        v4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int h = 0; h < PW / 4; ++h) {
+          const T av = PB[(tr * 16 + l15) * PW + 4 * h + l4];
+          const T bv = (colg >= jn) ? PB[colg * PW + 4 * h + l4] : zero;
+          acc = Num<T>::mfma(av, bv, acc);
+        }
         if (colg >= jn) {
           T* Cp = Wk + (tr * 16) * PLD + colg;
 #pragma unroll
