@@ -564,8 +564,14 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
   h->nb = nb;
   if (const char* e = getenv("GPX_NB_SHARD")) h->nb_shard_env = atoi(e);
   if (h->nb_shard_env < 128 || h->nb_shard_env > 2048 || h->nb_shard_env % 128 != 0) h->nb_shard_env = 0;
-  if (const char* e = getenv("GPX_NB_SOLVE")) h->nb_solve = atoi(e);
-  if (const char* e = getenv("GPX_NB_PRED")) h->nb_pred = atoi(e);
+  // tuning overrides; anything that is not a multiple of 128 in [128, 2048] is ignored
+  auto block_env = [](const char* name, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    return (v >= 128 && v <= 2048 && v % 128 == 0) ? v : dflt;
+  };
+  h->nb_solve = block_env("GPX_NB_SOLVE", h->nb_solve);
+  h->nb_pred = block_env("GPX_NB_PRED", h->nb_pred);
   int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(cfg->device) != hipSuccess ||
       hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
