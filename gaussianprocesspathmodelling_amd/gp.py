@@ -37,7 +37,7 @@ class GP:
     dtype : "float64" | "float32" (everything, including the factorisation, in fp32:
         the mixed-precision study of BASELINE.json configs[4]; not a 1e-6 path)
     device : HIP device ordinal (default: LOCAL_RANK or 0)
-    block : Cholesky panel width nb (multiple of 128; 0 = library default 512)
+    block : Cholesky panel width nb (multiple of 128, at most 2048; 0 = library default 1024)
     max_tries : jitter escalations (x10 each) before ``LinAlgError``
     profile : record per-launch timings of the Cholesky sub-phases
     world, rank : row-block shard of ONE Gram matrix over ``world`` processes (one per GPU).
