@@ -93,9 +93,12 @@ def cpu_baseline(n_sample=24576):
     """Oracle fit+predict on the host cores, bounded sample (about 10-30 s)."""
     import numpy as np
     from oracle.gp_oracle import OracleGP
+    nthreads = None
     try:
         from threadpoolctl import threadpool_info
-        blas = [f"{p.get('internal_api')}:{p.get('num_threads')}" for p in threadpool_info()]
+        info = threadpool_info()
+        blas = [f"{p.get('internal_api')}:{p.get('num_threads')}" for p in info]
+        nthreads = max((int(p.get("num_threads") or 0) for p in info), default=0) or None
     except Exception:
         blas = []
     X, y, Xs = synthetic(n_sample, DIM, M_TEST, 12345)
@@ -109,11 +112,11 @@ def cpu_baseline(n_sample=24576):
     # extrapolate each phase to N=65536 by its algorithmic work
     est = (tm["kbuild"] * r ** 2 + tm["chol"] * r ** 3 + tm["solve"] * r ** 2
            + (tm["kstar"] + tm["mean"]) * r + (tm["trsm"] + tm["var"]) * r ** 2) * 1e-3
-    cores = os.cpu_count() or 1
+    cores = nthreads or os.cpu_count() or 1      # the threads the BLAS actually runs (host has more CPUs)
     return {
         "value": (n_sample + M_TEST) / (t2 - t0), "unit": "points/s", "cores": cores,
         "kind": "port",
-        "sample": (f"oracle/gp_oracle.py (NumPy/SciPy, BLAS threads {blas}) full fit+predict at "
+        "sample": (f"oracle/gp_oracle.py (NumPy/SciPy, BLAS threads {blas}, host os.cpu_count()={os.cpu_count()}) full fit+predict at "
                    f"N={n_sample} d={DIM} M={M_TEST} RBF fp64, same generator: fit {t1 - t0:.2f} s "
                    f"(kbuild {tm['kbuild']:.0f} ms, chol {tm['chol']:.0f} ms, solve {tm['solve']:.0f} ms), "
                    f"predict {t2 - t1:.2f} s; phase-wise extrapolation to N={N_TRAIN}: "
