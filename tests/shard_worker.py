@@ -3,6 +3,8 @@ RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment.
   MODE = oracle   NumPy restatement of the schedule (CPU, gloo)
   MODE = callbacks  the ctypes host-collective callbacks on numpy buffers (CPU, gloo)
   MODE = gpu      the HIP path, ranks sharing one GPU, host transport over gloo
+  MODE = c4       BASELINE.json configs[3] shape (Matern-5/2, d=3, SURVEY.md §8d hyper-parameters,
+                  distributed solves) at a size that fits one GPU; saves what the §8d checks need
 """
 import ctypes as C
 import os
@@ -58,6 +60,26 @@ def main():
             mean, var = gp.predict(Xs)
             res = dict(mean=mean, var=var, alpha=gp.alpha_, logdet=gp.log_det_, info=gp.info_,
                        comm_ms=gp.timings_["comm"])
+    elif mode == "c4":
+        if nb > 0:
+            os.environ["GPX_NB_SHARD"] = str(nb)
+        else:
+            os.environ.pop("GPX_NB_SHARD", None)
+        import time
+        from gaussianprocesspathmodelling_amd import GP
+        X, y, Xs = synthetic_problem(N, 3, M, seed=12345)          # the SURVEY.md §8(d) generator
+        rows = np.random.default_rng(1).choice(N, min(N, 1024), replace=False)
+        with GP("matern52", 0.25, 1.5, 1e-2, jitter=0.0, device=0, world=world, rank=rank, comm="host") as gp:
+            t0 = time.perf_counter()
+            gp.fit(X, y)
+            t1 = time.perf_counter()
+            mean, var = gp.predict(Xs)
+            t2 = time.perf_counter()
+            mean_t, var_t = gp.predict(X[rows])
+            tm = gp.timings_
+            res = dict(mean=mean, var=var, alpha=gp.alpha_, logdet=gp.log_det_, info=gp.info_, rows=rows,
+                       mean_t=mean_t, var_t=var_t, fit_s=t1 - t0, predict_s=t2 - t1, comm_ms=tm["comm"],
+                       chol_ms=tm["chol"])
     np.savez(out + f".rank{rank}.npz", **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -39,6 +39,10 @@ def staircase(tm, tn, P, tpb, c):
     (16, 4, 2, 4, 0),           # the STRIP: only one block column wide
     (5, 3, 3, 1, 2),
     (256, 2040, 8, 8, 7),
+    (256, 2048, 8, 8, 0),       # BASELINE.json configs[3] per rank: N = 262144, P = 8, nb = 1024
+    (256, 2048, 8, 8, 8),       #   -> 256 local tile rows x 2048 tile columns, every offset class
+    (248, 1984, 8, 8, 3),
+    (256, 8, 8, 8, 5),          #   its STRIP (one block column)
 ])
 def test_staircase_map_is_a_bijection(gpx, tm, tn, P, tpb, c):
     pairs = tile_map(gpx, 1, tm, tn, P, tpb, c)
