@@ -10,18 +10,21 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgpx.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 KERNEL_IDS = {"rbf": 0, "matern52": 1}
 DTYPE_IDS = {"float64": 0, "float32": 1}
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_PROFILE = 1
+TRANSPORT_IDS = {None: 0, "auto": 0, "rccl": 1, "local": 2}
+MAX_GROUP = 8
 
 
 class GpxConfig(C.Structure):
     _fields_ = [("kernel", C.c_int32), ("dtype", C.c_int32), ("device", C.c_int32),
                 ("block", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
-                ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("flags", C.c_int32), ("ndev", C.c_int32), ("devices", C.c_int32 * MAX_GROUP),
+                ("transport", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class GpxTimings(C.Structure):
@@ -73,6 +76,7 @@ SIGNATURES = {
     "gpx_gemm_nt": (C.c_int, [_PD, C.c_int64, C.c_int64, _PD, _PD, C.c_int64, C.c_int32]),
     "gpx_debug_tile_map": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]),
+    "gpx_debug_local_hub": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "gpx_mfma_probe": (C.c_int, [_PD, _PD, _PD]),
     "gpx_mfma_probe_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gpx_microbench": (C.c_int, [_PD, _PD]),

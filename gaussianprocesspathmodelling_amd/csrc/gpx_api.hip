@@ -47,7 +47,8 @@ struct DevBuf {
   size_t cap = 0;
 };
 
-struct Comm;  // gpx_shard.inc
+struct Comm;   // gpx_shard.inc
+struct Group;  // gpx_group.inc
 
 }  // namespace
 
@@ -70,7 +71,10 @@ struct gpx_handle {
   // predict state
   DevBuf Q, Qs, VT, MT, var, meanout;
   // row-block shard (world > 1)
-  Comm* comm = nullptr;  // RCCL or host-callback transport (gpx_shard.inc)
+  Comm* comm = nullptr;  // RCCL, in-process or host-callback transport (gpx_shard.inc)
+  Group* group = nullptr;    // ndev > 1: this handle only fronts per-device member handles (gpx_group.inc)
+  bool in_group = false;     // a member of a group: inputs may live on another device of the process
+  bool discard_out = false;  // a member with rank > 0: rank 0 delivers the (identical) results
   void* zT = nullptr;      // z^T = (L^-1 y)^T (64 x ld): the bordered rows of the K buffer
   void* alphaT = nullptr;  // alpha^T (64 x ld): AT (computed on demand from z^T) or YT (shard)
   bool alpha_ready = false;
@@ -199,8 +203,8 @@ void diag_enqueue(T* A, int64_t ld, int64_t o, int nbp, T* Winv, int* info, int6
 // stored there as rows ("bordered matrix"), they leave the factorisation as
 // z^T = (L^-1 y)^T — the forward substitution costs no serial pass of its own.
 template <typename T>
-void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T* P0, T* P1,
-                  int64_t ldp, int* info, int64_t gidx0, bool profile, int64_t nx = 0) {
+int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T* P0, T* P1,
+                 int64_t ldp, int* info, int64_t gidx0, bool profile, int64_t nx = 0) {
   hipStream_t s0 = h->st, s1 = h->st2;
   T* Pbuf[2] = {P0, P1};
   // prologue: panel 0 on the main stream
@@ -235,9 +239,12 @@ void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T
         launch_gemm_nt<T>(nx % 128 == 0 && ntrail % 128 == 0 ? 128 : 64, A + n * ld + t0, ld,
                           Pc + ntrail * ldp, ldp, Pc, ldp, nx, ntrail, nbp, 0, 0, s0);
     }
+    // the two streams touch the same matrix: an event that cannot be created / recorded /
+    // waited on must fail the call, never let the streams run unordered
     hipEvent_t e_strip = next_event(h), e_panel = next_event(h);
-    (void)hipEventRecord(e_strip, s0);
-    (void)hipStreamWaitEvent(s1, e_strip, 0);
+    if (!e_strip || !e_panel) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+    HIPCHK(h, hipEventRecord(e_strip, s0));
+    HIPCHK(h, hipStreamWaitEvent(s1, e_strip, 0));
     {  // look-ahead stream: factor diagonal block p+1, solve panel p+1
       {
         PhaseScope ps(h, &h->tm.chol_diag, profile, s1);
@@ -249,7 +256,7 @@ void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T
                            Winv + (t0 / KB) * (KB * KB), nbn, Pn, ldp, s1);
       }
     }
-    (void)hipEventRecord(e_panel, s1);
+    HIPCHK(h, hipEventRecord(e_panel, s1));
     if (nrest > 0) {  // REST: lower triangle of the trailing matrix beyond the strip
       PhaseScope ps(h, &h->tm.chol_syrk, profile);
       launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + (t0 + nbn), ld, Pc + (int64_t)nbn * ldp, ldp,
@@ -257,8 +264,9 @@ void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T
       h->tm.syrk_flops += (double)nrest * (double)(nrest + 1) * (double)nbp;
       h->tm.syrk_launches += 1;
     }
-    (void)hipStreamWaitEvent(s0, e_panel, 0);
+    HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
   }
+  return GPX_OK;
 }
 
 // XT (rows x n, ld) <- XT * L^-T   (i.e. X <- L^-1 X for X = XT^T), block forward substitution.
@@ -267,8 +275,8 @@ void chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T
 // columns of block p+1) and the REST; the high-priority stream solves block p+1 while
 // the main stream runs the rest of update p (disjoint columns of XT).
 template <typename T>
-void solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld, int64_t n, int nb,
-                       const T* Winv) {
+int solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld, int64_t n, int nb,
+                      const T* Winv) {
   hipStream_t s0 = h->st, s1 = h->st2;
   const int tile = (rows % 128 == 0) ? 128 : 64;
   if (rows < 128 || !s1) {
@@ -281,7 +289,7 @@ void solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t l
         launch_gemm_nt<T>((ntrail % 128 == 0) ? tile : 64, XT + o + nbp, ld, XT + o, ld,
                           L + (o + nbp) * ld + o, ld, rows, ntrail, nbp, 0, 0, s0);
     }
-    return;
+    return GPX_OK;
   }
   launch_trsm_rlt<T>(XT, ld, rows, L, ld, Winv, (int)std::min<int64_t>(nb, n), nullptr, 0, s0);
   for (int64_t o = 0; o < n; o += nb) {
@@ -293,16 +301,18 @@ void solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t l
     const int tl = (nbn % 128 == 0 && nrest % 128 == 0) ? tile : 64;
     launch_gemm_nt<T>(tl, XT + t0, ld, XT + o, ld, L + t0 * ld + o, ld, rows, nbn, nbp, 0, 0, s0);  // STRIP
     hipEvent_t e_strip = next_event(h), e_panel = next_event(h);
-    (void)hipEventRecord(e_strip, s0);
-    (void)hipStreamWaitEvent(s1, e_strip, 0);
+    if (!e_strip || !e_panel) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+    HIPCHK(h, hipEventRecord(e_strip, s0));
+    HIPCHK(h, hipStreamWaitEvent(s1, e_strip, 0));
     launch_trsm_rlt<T>(XT + t0, ld, rows, L + t0 * ld + t0, ld, Winv + (t0 / KB) * (KB * KB), nbn, nullptr,
                        0, s1);
-    (void)hipEventRecord(e_panel, s1);
+    HIPCHK(h, hipEventRecord(e_panel, s1));
     if (nrest > 0)  // REST
       launch_gemm_nt<T>(tl, XT + t0 + nbn, ld, XT + o, ld, L + (t0 + nbn) * ld + o, ld, rows, nrest, nbp, 0,
                         0, s0);
-    (void)hipStreamWaitEvent(s0, e_panel, 0);
+    HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
   }
+  return GPX_OK;
 }
 
 // XT (rows x n, ld) <- XT * L^-1   (X <- L^-T X), block back substitution; rows multiple of 64
@@ -320,9 +330,11 @@ void solve_bwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t l
 
 int copy_in(gpx_handle* h, void* dst, const void* src, size_t bytes, int mem_kind) {
   if (bytes == 0) return GPX_OK;
-  HIPCHK(h, hipMemcpyAsync(dst, src, bytes,
-                           mem_kind == GPX_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
-                           h->st));
+  // group members: a device pointer of the caller lives on ONE of the group's devices
+  const hipMemcpyKind kind = mem_kind == GPX_MEM_HOST ? hipMemcpyHostToDevice
+                             : h->in_group            ? hipMemcpyDefault
+                                                      : hipMemcpyDeviceToDevice;
+  HIPCHK(h, hipMemcpyAsync(dst, src, bytes, kind, h->st));
   return GPX_OK;
 }
 
@@ -334,12 +346,35 @@ int copy_out(gpx_handle* h, void* dst, const void* src, size_t bytes, int mem_ki
   return GPX_OK;
 }
 
+// Rows of K* / V^T per batch of query points.  Query rows are independent, so predicting in
+// batches is numerically identical to one pass; the V^T buffer is the only O(M N) allocation
+// of predict (M = 65536 at N = 131072 would be 69 GB beside the 137 GB factor), so it is capped:
+// GPX_PRED_BATCH rows (default 8192, a multiple of 128), and — where every rank decides for
+// itself (no collective inside the batch loop) — shrunk to what the card has left.
+int64_t pred_batch_rows(gpx_handle* h, int64_t Mpad, size_t row_bytes, bool may_shrink) {
+  int64_t cap = 8192;
+  if (const char* e = getenv("GPX_PRED_BATCH")) {
+    const long v = atol(e);
+    if (v >= 128 && v <= (1L << 22)) cap = v / 128 * 128;
+  }
+  if (may_shrink) {
+    size_t freeb = 0, totalb = 0;
+    if (hipMemGetInfo(&freeb, &totalb) == hipSuccess) {
+      const double avail = 0.8 * ((double)freeb + (double)h->VT.cap);
+      const int64_t fit = (int64_t)(avail / (double)row_bytes) / 128 * 128;
+      cap = std::max<int64_t>(128, std::min(cap, fit));
+    }
+  }
+  return std::min(cap, Mpad);
+}
+
 template <typename T>
 int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_t mem_kind);
 
 }  // namespace
 
 #include "gpx_shard.inc"
+#include "gpx_group.inc"
 
 namespace {
 
@@ -399,8 +434,9 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
     {
       PhaseScope ps(h, &tm.chol);
       launch_pack_rhs<T>((const T*)h->Y.p, N, k, dYT, ld, Npad, (int)NX, h->st);
-      chol_enqueue<T>(h, dK, ld, Npad, h->nb, (T*)h->Winv.p, (T*)h->P.p,
-                      (T*)h->P.p + (Npad + NX) * ldp, ldp, dInfo, 0, profile, NX);
+      if ((rc = chol_enqueue<T>(h, dK, ld, Npad, h->nb, (T*)h->Winv.p, (T*)h->P.p,
+                                (T*)h->P.p + (Npad + NX) * ldp, ldp, dInfo, 0, profile, NX)))
+        return rc;
     }
     // The forward substitution happened inside the factorisation (bordered rows).  The
     // back substitution alpha = L^-T z is NOT on the fit+predict path: the posterior mean is
@@ -447,45 +483,50 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
   const int d = h->d, k = h->k;
   const int64_t Mpad = round_up(M, TILE);
   const int64_t ldm = Mpad + LD_SKEW;
+  const int64_t MB = pred_batch_rows(h, Mpad, (size_t)ld * sizeof(T), true);
   gpx_timings& tm = h->tm;
   int rc;
   if ((rc = ensure(h, h->Q, (size_t)M * d * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->Qs, (size_t)Mpad * d * sizeof(T)))) return rc;
-  if ((rc = ensure(h, h->VT, (size_t)Mpad * ld * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->VT, (size_t)MB * ld * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->MT, (size_t)RHS_ROWS * ldm * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->meanout, (size_t)M * k * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->var, (size_t)Mpad * sizeof(T)))) return rc;
   T* dVT = (T*)h->VT.p;
   const T* dK = (const T*)h->Lfac;
   const T* dWinv = (const T*)h->Winv.p;
+  if (!want_var && (rc = ensure_alpha<T>(h))) return rc;  // mean only: K* alpha with the cached alpha
+  const T* rhsT = (const T*)(want_var ? h->zT : h->alphaT);
   {
     PhaseScope ps(h, &tm.kstar);
     if ((rc = copy_in(h, h->Q.p, Xq, (size_t)M * d * sizeof(T), mem_kind))) return rc;
     launch_scale_points<T>((const T*)h->Q.p, M, Mpad, d, (const double*)h->ls.p, h->n_ls,
                         (T*)h->Qs.p, h->st);
-    launch_kbuild_cross<T>(h->cfg.kernel, (const T*)h->Qs.p, M, Mpad, (const T*)h->Xs.p, N,
-                        Npad, d, h->sf2, dVT, ld, h->st);
   }
-  if (want_var) {
+  for (int64_t m0 = 0; m0 < Mpad; m0 += MB) {  // batches of query points through one V^T buffer
+    const int64_t mp = std::min(MB, Mpad - m0);       // padded rows of this batch
+    const int64_t mv = std::min<int64_t>(mp, M - m0);  // valid rows
     {
+      PhaseScope ps(h, &tm.kstar);
+      launch_kbuild_cross<T>(h->cfg.kernel, (const T*)h->Qs.p + m0 * d, mv, mp, (const T*)h->Xs.p, N,
+                          Npad, d, h->sf2, dVT, ld, h->st);
+    }
+    if (want_var) {
       PhaseScope ps(h, &tm.trsm);
-      solve_fwd_enqueue<T>(h, dVT, Mpad, dK, ld, Npad, h->nb_pred, dWinv);
+      if ((rc = solve_fwd_enqueue<T>(h, dVT, mp, dK, ld, Npad, h->nb_pred, dWinv))) return rc;
     }
-    {  // mean^T (64 x Mpad) = z^T (64 x Npad) * V   (mu = K* K^-1 y = V^T z)
+    {  // with the variance: mean^T (64 x mp) = z^T (64 x Npad) * V   (mu = K* K^-1 y = V^T z);
+       // mean only: alpha^T * K*^T
       PhaseScope ps(h, &tm.mean);
-      launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->zT, ld, dVT, ld, RHS_ROWS, Mpad, Npad, 0, 1,
-                        h->st);
-      launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, k, 1.0, (T*)h->meanout.p, h->st);
+      launch_gemm_nt<T>(64, (T*)h->MT.p + m0, ldm, rhsT, ld, dVT, ld, RHS_ROWS, mp, Npad, 0, 1, h->st);
     }
-    {
+    if (want_var) {
       PhaseScope ps(h, &tm.var);
-      launch_var_rows<T>(dVT, ld, M, Npad, h->sf2, (T*)h->var.p, h->st);
+      launch_var_rows<T>(dVT, ld, mv, Npad, h->sf2, (T*)h->var.p + m0, h->st);
     }
-  } else {  // mean only: K* alpha with the (cached) back-substituted alpha
-    if ((rc = ensure_alpha<T>(h))) return rc;
+  }
+  {
     PhaseScope ps(h, &tm.mean);
-    launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->alphaT, ld, dVT, ld, RHS_ROWS, Mpad, Npad, 0, 1,
-                      h->st);
     launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, k, 1.0, (T*)h->meanout.p, h->st);
   }
   return GPX_OK;
@@ -550,17 +591,27 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
     return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: the row-block shard is fp64 only");
   if (cfg->world < 1 || cfg->world > 64 || cfg->rank < 0 || cfg->rank >= cfg->world)
     return fail(nullptr, GPX_E_ARG, "gpx_create: need 1 <= world <= 64 and 0 <= rank < world");
+  if (cfg->ndev < 0 || cfg->ndev > GPX_MAX_GROUP)
+    return fail(nullptr, GPX_E_ARG, "gpx_create: need 0 <= ndev <= GPX_MAX_GROUP");
   const int nb = cfg->block == 0 ? 1024 : cfg->block;
   if (nb < 128 || nb > 2048 || nb % 128 != 0)
     return fail(nullptr, GPX_E_ARG, "gpx_create: block must be a multiple of 128 in [128, 2048]");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, GPX_E_HIP, "gpx_create: no HIP device visible (libgpx has no CPU fallback)");
-  if (cfg->device < 0 || cfg->device >= ndev)
+  if (cfg->ndev > 1) {
+    for (int i = 0; i < cfg->ndev; ++i)
+      if (cfg->devices[i] < 0 || cfg->devices[i] >= ndev)
+        return fail(nullptr, GPX_E_ARG, "gpx_create: group device ordinal out of range");
+    return create_group(out, cfg);
+  }
+  const int device = cfg->ndev == 1 ? cfg->devices[0] : cfg->device;
+  if (device < 0 || device >= ndev)
     return fail(nullptr, GPX_E_ARG, "gpx_create: device ordinal out of range");
   gpx_handle* h = new (std::nothrow) gpx_handle();
   if (!h) return fail(nullptr, GPX_E_NOMEM, "gpx_create: out of host memory");
   h->cfg = *cfg;
+  h->cfg.device = device;
   h->nb = nb;
   if (const char* e = getenv("GPX_NB_SHARD")) h->nb_shard_env = atoi(e);
   if (h->nb_shard_env < 128 || h->nb_shard_env > 2048 || h->nb_shard_env % 128 != 0) h->nb_shard_env = 0;
@@ -573,7 +624,7 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
   h->nb_solve = block_env("GPX_NB_SOLVE", h->nb_solve);
   h->nb_pred = block_env("GPX_NB_PRED", h->nb_pred);
   int prio_lo = 0, prio_hi = 0;
-  if (hipSetDevice(cfg->device) != hipSuccess ||
+  if (hipSetDevice(device) != hipSuccess ||
       hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithPriority(&h->st2, hipStreamNonBlocking, prio_hi) != hipSuccess) {
@@ -587,6 +638,11 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
 
 void gpx_destroy(gpx_handle* h) {
   if (!h) return;
+  if (h->group) {
+    destroy_group(h);
+    delete h;
+    return;
+  }
   (void)hipSetDevice(h->cfg.device);
   if (h->st) (void)hipStreamSynchronize(h->st);
   if (h->st2) (void)hipStreamSynchronize(h->st2);
@@ -617,6 +673,7 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
   for (int i = 0; i < n_ls; ++i)
     if (!(lengthscale[i] > 0.0)) return fail(h, GPX_E_ARG, "gpx_fit: lengthscale must be > 0");
   if (N > (int64_t)INT_MAX - 4096) return fail(h, GPX_E_ARG, "gpx_fit: N too large");
+  if (h->group) return group_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->fitted = false;
   h->err.clear();
@@ -636,6 +693,7 @@ int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var,
   if (!Xq || !mean || M <= 0) return fail(h, GPX_E_ARG, "gpx_predict: bad argument");
   if (mem_kind != GPX_MEM_HOST && mem_kind != GPX_MEM_DEVICE)
     return fail(h, GPX_E_ARG, "gpx_predict: bad mem_kind");
+  if (h->group) return group_predict(h, Xq, M, mean, var, mem_kind);
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->err.clear();
   h->phases.clear();
@@ -648,6 +706,12 @@ int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var,
 int gpx_get_alpha(gpx_handle* h, void* out) {
   if (!h) return GPX_E_ARG;
   if (!h->fitted || !out) return fail(h, GPX_E_ARG, "gpx_get_alpha: no fit or null output");
+  if (h->group) {  // alpha is replicated (or solved on demand from the replicated factor): rank 0 has it
+    gpx_handle* m0 = h->group->members[0];
+    const int rc = gpx_get_alpha(m0, out);
+    if (rc != GPX_OK) h->err = m0->err;
+    return rc;
+  }
   HIPCHK(h, hipSetDevice(h->cfg.device));
   if (h->cfg.dtype == GPX_F32) return alpha_impl<float>(h, out);
   return alpha_impl<double>(h, out);
@@ -656,13 +720,13 @@ int gpx_get_alpha(gpx_handle* h, void* out) {
 int gpx_logdet(gpx_handle* h, double* out) {
   if (!h) return GPX_E_ARG;
   if (!h->fitted || !out) return fail(h, GPX_E_ARG, "gpx_logdet: no fit or null output");
-  *out = h->logdet;
+  *out = h->group ? h->group->members[0]->logdet : h->logdet;
   return GPX_OK;
 }
 
 int gpx_get_timings(gpx_handle* h, gpx_timings* out) {
   if (!h || !out) return GPX_E_ARG;
-  *out = h->tm;
+  *out = h->group ? h->group->members[0]->tm : h->tm;  // a group reports rank 0's clocks
   return GPX_OK;
 }
 
@@ -759,7 +823,7 @@ int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info) {
   TCHK(hipMalloc(&dInfo, 64));
   TCHK(hipMemcpy2DAsync(dA, (size_t)ld * 8, A, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice, st));
   TCHK(hipMemcpyAsync(dInfo, &hinfo, sizeof(int), hipMemcpyHostToDevice, st));
-  chol_enqueue(&sc.h, dA, ld, n, nb, dW, dP, dP + n * ldp, ldp, dInfo, 0, false);
+  if ((rc = chol_enqueue(&sc.h, dA, ld, n, nb, dW, dP, dP + n * ldp, ldp, dInfo, 0, false))) goto done;
   TCHK(hipMemcpy2DAsync(A, (size_t)n * 8, dA, (size_t)ld * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost, st));
   TCHK(hipMemcpyAsync(&hinfo, dInfo, sizeof(int), hipMemcpyDeviceToHost, st));
   TCHK(hipStreamSynchronize(st));

@@ -105,6 +105,8 @@ void launch_scatter_local(const double* Loc, int64_t ldl, double* Full, int64_t 
 void launch_add_block(double* dst, int64_t ldd, const double* src, int64_t lds, int rows, int cols,
                       double sign, hipStream_t st);
 void launch_add_scalar(double* p, int64_t count, double v, hipStream_t st);
+// dst[i] = op over q < P of src[q*count + i] in rank order (op 0 sum, 1 min); dst may not alias src
+void launch_reduce_ranks(const double* src, double* dst, int P, int64_t count, int op, hipStream_t st);
 // out[0] += 2 * sum_i log(A[i][i]), i < n (one diagonal block)
 void launch_logdet_acc(const double* A, int64_t lda, int n, double* out, hipStream_t st);
 

@@ -181,6 +181,21 @@ __global__ __launch_bounds__(256) void add_scalar_kernel(double* p, int64_t coun
     p[i] += v;
 }
 
+// dst[i] = op over q < P of src[q * count + i], in rank order (in-process transport: every rank
+// that reduces gets bit-identical results); op 0 = sum, 1 = min
+__global__ __launch_bounds__(256) void reduce_ranks_kernel(const double* __restrict__ src,
+                                                          double* __restrict__ dst, int P, int64_t count,
+                                                          int op) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    double v = src[i];
+    for (int q = 1; q < P; ++q) {
+      const double w = src[(int64_t)q * count + i];
+      v = op == 1 ? fmin(v, w) : v + w;
+    }
+    dst[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void logdet_acc_kernel(const double* __restrict__ A, int64_t lda,
                                                         int n, double* __restrict__ out) {
   __shared__ double red[4];
@@ -229,6 +244,12 @@ void launch_add_scalar(double* p, int64_t count, double v, hipStream_t st) {
   if (count <= 0) return;
   const int64_t bx = (count + 255) / 256;
   hipLaunchKernelGGL(add_scalar_kernel, dim3((unsigned)(bx > 1024 ? 1024 : bx)), dim3(256), 0, st, p, count, v);
+}
+
+void launch_reduce_ranks(const double* src, double* dst, int P, int64_t count, int op, hipStream_t st) {
+  if (count <= 0) return;
+  const int64_t bx = (count + 255) / 256;
+  hipLaunchKernelGGL(reduce_ranks_kernel, dim3((unsigned)(bx > 2048 ? 2048 : bx)), dim3(256), 0, st, src, dst, P, count, op);
 }
 
 void launch_logdet_acc(const double* A, int64_t lda, int n, double* out, hipStream_t st) {

@@ -37,6 +37,17 @@ class GP:
     dtype : "float64" | "float32" (everything, including the factorisation, in fp32:
         the mixed-precision study of BASELINE.json configs[4]; not a 1e-6 path)
     device : HIP device ordinal (default: LOCAL_RANK or 0)
+    devices : several GPUs from ONE ordinary Python process: an int n (devices
+        0..n-1) or a list of HIP ordinals.  The Gram matrix is sharded in block-cyclic row blocks
+        over them; one worker thread per device lives inside ``fit`` / ``predict``, which stay
+        plain blocking calls — no launcher, no ``torch.distributed``.  ``devices=1`` / ``[i]`` is
+        the single-GPU path on that device.
+    transport : how the devices of a ``devices=`` group exchange panels: "rccl"
+        (``ncclCommInitAll`` inside the process; distinct devices only), "local" (peer copies
+        and hipEvents between the ranks' streams, nothing but HIP), None/"auto" = rccl when the
+        devices are distinct, else local.
+    oversubscribe : allow ``devices=n`` with fewer than n GPUs visible: ordinals wrap around, so
+        several ranks share a GPU over the local transport (how the one-GPU tests run 2..8 ranks)
     block : Cholesky panel width nb (multiple of 128, at most 2048; 0 = library default 1024)
     max_tries : jitter escalations (x10 each) before ``LinAlgError``
     profile : record per-launch timings of the Cholesky sub-phases
@@ -50,7 +61,8 @@ class GP:
 
     def __init__(self, kernel="rbf", lengthscale=1.0, variance=1.0, noise=1e-2, jitter=None,
                  dtype="float64", device=None, block=0, max_tries=3, profile=False,
-                 world=1, rank=0, comm=None, group=None):
+                 world=1, rank=0, comm=None, group=None, devices=None, transport=None,
+                 oversubscribe=False):
         if kernel not in _abi.KERNEL_IDS:
             raise ValueError(f"unknown kernel {kernel!r}; expected one of {sorted(_abi.KERNEL_IDS)}")
         if dtype not in _abi.DTYPE_IDS:
@@ -74,9 +86,19 @@ class GP:
         self.device = int(device)
         self._lib = _abi.load()
         self.world, self.rank = int(world), int(rank)
+        if transport not in _abi.TRANSPORT_IDS:
+            raise ValueError(f"unknown transport {transport!r}; expected rccl / local / auto")
+        self.devices = self._resolve_devices(devices, oversubscribe)
+        if len(self.devices) > 1 and (self.world != 1 or comm is not None):
+            raise ValueError("devices= (one process, several GPUs) and world=/comm= (one process per GPU) "
+                             "are two different process models: pick one")
+        if self.devices:
+            self.device = self.devices[0]
         cfg = _abi.GpxConfig(kernel=_abi.KERNEL_IDS[kernel], dtype=_abi.DTYPE_IDS[dtype],
                              device=self.device, block=self.block, rank=self.rank, world=self.world,
-                             flags=_abi.FLAG_PROFILE if profile else 0, reserved=0)
+                             flags=_abi.FLAG_PROFILE if profile else 0, ndev=len(self.devices),
+                             devices=(C.c_int32 * _abi.MAX_GROUP)(*self.devices),
+                             transport=_abi.TRANSPORT_IDS[transport])
         h = C.c_void_p()
         rc = self._lib.gpx_create(C.byref(h), C.byref(cfg))
         if rc != 0:
@@ -89,6 +111,27 @@ class GP:
         self._host_comm = None
         if self.world > 1 or comm is not None:
             self._init_comm(comm, group)
+
+    def _resolve_devices(self, devices, oversubscribe):
+        if devices is None:
+            return []
+        if isinstance(devices, (int, np.integer)):
+            n = int(devices)
+            if n < 1:
+                raise ValueError("devices must be >= 1")
+            devs = list(range(n))
+        else:
+            devs = [int(v) for v in devices]
+            if not devs:
+                raise ValueError("devices must not be empty")
+        if len(devs) > _abi.MAX_GROUP:
+            raise ValueError(f"at most {_abi.MAX_GROUP} devices per group")
+        if oversubscribe:
+            cnt = C.c_int(0)
+            self._lib.gpx_device_count(C.byref(cnt))
+            if cnt.value > 0:
+                devs = [v % cnt.value for v in devs]
+        return devs
 
     def _init_comm(self, comm, group):
         from . import dist as gdist

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GPX_ABI_VERSION 1
+#define GPX_ABI_VERSION 2
 
 /* kernel family — SURVEY.md §8 row a1 (nearest reference code: the pairwise
  * distance loop trajectories.calc_distance, GPmap.py:114-121, and the unused
@@ -52,15 +52,31 @@ extern "C" {
 
 typedef struct gpx_handle gpx_handle;
 
+/* transport of a single-process device group (gpx_config.ndev > 1) */
+#define GPX_TRANSPORT_AUTO 0  /* RCCL when the listed devices are distinct, else LOCAL          */
+#define GPX_TRANSPORT_RCCL 1  /* ncclCommInitAll inside the process, one communicator per device */
+#define GPX_TRANSPORT_LOCAL 2 /* stream-ordered peer copies between the ranks' device buffers,   \
+                                 hipEvents between their streams; no library besides HIP.  Also   \
+                                 valid with one device listed several times (ranks share it).    */
+#define GPX_MAX_GROUP 8
+
 typedef struct gpx_config {
   int32_t kernel;  /* GPX_KERNEL_*                                   */
   int32_t dtype;   /* GPX_F64 | GPX_F32                              */
-  int32_t device;  /* HIP device ordinal this handle computes on     */
+  int32_t device;  /* HIP device ordinal this handle computes on (ndev <= 1)                 */
   int32_t block;   /* Cholesky panel width nb (multiple of 128, <= 2048), 0 = default (1024) */
-  int32_t rank;    /* this process' rank in the row-block shard (0 if world==1)    */
-  int32_t world;   /* number of GPUs sharing the Gram matrix (1 = unsharded)       */
+  int32_t rank;    /* process-per-GPU shard: this process' rank (0 if world==1)              */
+  int32_t world;   /* process-per-GPU shard: number of processes sharing the Gram matrix     */
   int32_t flags;   /* GPX_FLAG_*                                     */
-  int32_t reserved;
+  /* Single-process multi-GPU (SURVEY.md §8b "Threading"): ndev > 1 makes the handle a GROUP —
+   * one rank per entry of devices[], one worker thread per rank inside the calling process,
+   * the same row-block-cyclic schedule as the process-per-GPU shard.  gpx_fit / gpx_predict /
+   * gpx_get_alpha / ... on the group handle are ordinary blocking calls of a plain caller (no
+   * launcher, no torch.distributed); rank/world must be 0/1 then. */
+  int32_t ndev;                     /* 0 or 1: one device (`device`);  2..GPX_MAX_GROUP: group */
+  int32_t devices[GPX_MAX_GROUP];   /* HIP ordinals of the group's ranks                       */
+  int32_t transport;                /* GPX_TRANSPORT_*                                         */
+  int32_t reserved[3];
 } gpx_config;
 
 /* per-phase wall times (ms, hipEvent on the handle's stream) of the LAST
@@ -102,7 +118,9 @@ int gpx_logdet(gpx_handle* h, double* out);
 int gpx_get_timings(gpx_handle* h, gpx_timings* out);
 
 /* ---- row-block sharding over RCCL ------------------------------ */
-/* One process per GPU.  Rank 0 calls gpx_comm_unique_id and ships the 128 bytes to
+/* Two process models run the same schedule: the single-process device group above
+ * (gpx_config.ndev) and one process per GPU (below).
+ * One process per GPU.  Rank 0 calls gpx_comm_unique_id and ships the 128 bytes to
  * the other ranks by any means (the Python host uses torch.distributed); every rank
  * then calls gpx_comm_init on its handle (created with the same world, own rank).  A
  * handle that owns a communicator — even a 1-rank one — runs the sharded schedule. */
@@ -161,6 +179,13 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs);
  * every owned tile must appear exactly once. */
 int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t tpb, int32_t c,
                        int32_t* out, int64_t cap, int64_t* count);
+/* host-only exercise of the rendezvous the LOCAL transport's rank threads use (no GPU needed):
+ * P threads run `rounds` barrier rounds, each checking that every rank published the round
+ * number; if abort_rank >= 0 that rank leaves at round abort_round and aborts the hub instead
+ * of arriving.  *completed = rounds every surviving rank finished; returns 0 when all threads
+ * came back (no deadlock) and saw consistent data, GPX_E_COMM otherwise. */
+int gpx_debug_local_hub(int32_t P, int32_t rounds, int32_t abort_rank, int32_t abort_round,
+                        int32_t* completed);
 
 #ifdef __cplusplus
 }

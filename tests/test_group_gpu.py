@@ -1,0 +1,128 @@
+"""GPU: the single-process multi-GPU surface of SURVEY.md §8b — ``GP(devices=...)`` called from
+this ordinary pytest process: no launcher, no torch.distributed.  The development box has ONE
+GPU, so the ranks share it (``oversubscribe`` / a repeated ordinal) over the LOCAL transport:
+peer copies and hipEvents between the ranks' streams, i.e. for the first time the look-ahead
+stream's exchanges really run concurrently with the main stream's trailing update."""
+import numpy as np
+import pytest
+
+from c4_util import C4, c4_checks, c4_run, single_gpu_c4
+from gaussianprocesspathmodelling_amd import GP, GpxError
+from oracle.gp_oracle import OracleGP, synthetic_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def check(mean, var, alpha, logdet, ref, mr, vr, sf2=1.5):
+    dm = np.abs(mean - mr) / np.maximum(np.abs(mr), 1e-6)
+    dv = np.abs(var - vr) / np.maximum(vr, 1e-6 * sf2)
+    assert dm.max() <= 1e-6 and dv.max() <= 1e-6, (dm.max(), dv.max())
+    assert np.max(np.abs(alpha - ref.alpha_)) <= 1e-7 * np.abs(ref.alpha_).max()
+    assert abs(logdet - ref.log_det_) <= 1e-9 * abs(ref.log_det_)
+
+
+@pytest.mark.parametrize("ndev,kernel,nb,N,M,repl", [
+    (2, "rbf", 128, 700, 90, 0), (2, "rbf", 128, 700, 90, 1),
+    (3, "matern52", 128, 700, 90, 0), (4, "rbf", 512, 3300, 130, 0), (4, "rbf", 512, 3300, 130, 1),
+    (8, "matern52", 128, 2000, 77, 0), (8, "rbf", 256, 5000, 300, 1),
+    (2, "rbf", 128, 100, 5, 0),            # one block: rank 1 owns no rows at all
+    (5, "rbf", 128, 250, 3, 1),            # two blocks on five ranks, fewer query points than ranks
+    (2, "rbf", 0, 9000, 200, -1),          # block height / mode chosen by the library
+])
+def test_devices_surface_matches_oracle(monkeypatch, ndev, kernel, nb, N, M, repl):
+    if nb:
+        monkeypatch.setenv("GPX_NB_SHARD", str(nb))
+    else:
+        monkeypatch.delenv("GPX_NB_SHARD", raising=False)
+    if repl >= 0:
+        monkeypatch.setenv("GPX_SHARD_REPLICATE", str(repl))
+    X, y, Xs = synthetic_problem(N, 3, M, seed=77)
+    ls = (0.3, 0.2, 0.25)
+    ref = OracleGP(kernel, ls, 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    with GP(kernel, ls, 1.5, 1e-2, jitter=0.0, devices=ndev, oversubscribe=True) as gp:
+        mean, var = gp.fit(X, y).predict(Xs)
+        check(mean, var, gp.alpha_, gp.log_det_, ref, mr, vr)
+        assert abs(gp.log_marginal_likelihood(y) - ref.log_marginal_likelihood()) <= 1e-9 * abs(ref.log_marginal_likelihood())
+        m2 = gp.predict(Xs, return_var=False)
+        assert np.max(np.abs(m2 - mean)) <= 1e-9 * max(1.0, np.abs(mean).max())
+        m3, v3 = gp.fit(X, y).predict(Xs)          # refit on the same group: buffers and events reused
+        assert np.array_equal(m3, mean) and np.array_equal(v3, var)
+
+
+def test_devices_list_and_single_entry():
+    X, y, Xs = synthetic_problem(900, 3, 40, seed=3)
+    ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    for devs in ([0], 1, [0, 0, 0]):
+        with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0, devices=devs, transport=None if devs != [0, 0, 0] else "local") as gp:
+            mean, var = gp.fit(X, y).predict(Xs)
+            check(mean, var, gp.alpha_, gp.log_det_, ref, mr, vr)
+    with pytest.raises(GpxError, match="distinct"):
+        GP(devices=[0, 0], transport="rccl")
+    with pytest.raises(GpxError, match="out of range"):
+        GP(devices=[0, 63])
+
+
+def test_devices_group_device_tensor_inputs_and_multi_output():
+    torch = pytest.importorskip("torch")
+    X, y, Xs = synthetic_problem(1100, 3, 64, seed=9)
+    Y = np.stack([y, np.cos(y)], axis=1)
+    ref = OracleGP("matern52", 0.3, 1.2, 2e-2, jitter=0.0).fit(X, Y)
+    mr, vr = ref.predict(Xs)
+    dev = torch.device("cuda:0")
+    with GP("matern52", 0.3, 1.2, 2e-2, jitter=0.0, devices=[0, 0, 0]) as gp:
+        gp.fit(torch.from_numpy(X).to(dev), torch.from_numpy(Y).to(dev))
+        mean, var = gp.predict(torch.from_numpy(Xs).to(dev))
+        assert mean.is_cuda and mean.shape == (64, 2)
+        for c in range(2):
+            check(mean[:, c].cpu().numpy(), var.cpu().numpy(), gp.alpha_[:, c], gp.log_det_,
+                  type("R", (), {"alpha_": ref.alpha_[:, c], "log_det_": ref.log_det_}), mr[:, c], vr, 1.2)
+
+
+def test_group_not_positive_definite_reports_pivot_on_every_rank():
+    X = np.zeros((300, 2))
+    X[:, 0] = np.repeat(np.linspace(0, 1, 150), 2)       # duplicated points, zero noise
+    y = np.sin(X[:, 0])
+    with GP("rbf", 0.5, 1.0, noise=0.0, jitter=0.0, max_tries=1, devices=[0, 0]) as gp:
+        with pytest.raises(np.linalg.LinAlgError):
+            gp.fit(X, y)
+        assert gp.info_ > 0
+
+
+def test_c4_shape_on_one_gpu_world8():
+    """BASELINE.json configs[3] code path with the P = 8 block-cyclic maps: Matern-5/2, d = 3,
+    distributed solves, library-chosen block height, N = 32768 on EIGHT ranks — threads of this
+    process sharing the one GPU (8 processes would exceed the box's process limit)."""
+    N, M = 32768, 1024
+    import os
+    os.environ["GPX_SHARD_REPLICATE"] = "0"
+    os.environ.pop("GPX_NB_SHARD", None)
+    try:
+        with GP(jitter=0.0, devices=[0] * 8, **C4) as gp:
+            r = c4_run(gp, N, M)
+            tm = gp.timings_
+    finally:
+        os.environ.pop("GPX_SHARD_REPLICATE", None)
+    resid = c4_checks([r], N, M, single_gpu_c4(N, M))
+    print(f"C4 shape, 8 ranks in one process, N={N}: residual {resid:.2e}, fit {tm['fit_total']:.0f} ms "
+          f"(chol {tm['chol']:.0f} ms, comm {tm['comm']:.0f} ms), predict {tm['predict_total']:.0f} ms")
+
+
+def test_c4_shape_group_world4_n65536_overlapped():
+    """The world-4, N = 65536 case of test_shard_gpu.py again, but through the in-process
+    transport: exchanges are stream-ordered (no host synchronisation per collective), so panel
+    p+1's broadcast / all-gather on the look-ahead stream overlap update p on the main stream."""
+    N, M = 65536, 1024
+    import os
+    os.environ["GPX_SHARD_REPLICATE"] = "0"
+    os.environ.pop("GPX_NB_SHARD", None)
+    try:
+        with GP(jitter=0.0, devices=[0] * 4, **C4) as gp:
+            r = c4_run(gp, N, M)
+            tm = gp.timings_
+    finally:
+        os.environ.pop("GPX_SHARD_REPLICATE", None)
+    resid = c4_checks([r], N, M, single_gpu_c4(N, M))
+    print(f"C4 shape, 4 ranks in one process, N={N}: residual {resid:.2e}, fit {tm['fit_total']:.0f} ms "
+          f"(chol {tm['chol']:.0f} ms, comm {tm['comm']:.0f} ms), predict {tm['predict_total']:.0f} ms")

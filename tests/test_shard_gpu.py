@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from gaussianprocesspathmodelling_amd import GP
-from oracle.gp_oracle import OracleGP, kernel_matrix, synthetic_problem
+from oracle.gp_oracle import OracleGP, synthetic_problem
+from c4_util import c4_checks, single_gpu_c4
 from shard_util import run_ranks
 
 pytestmark = pytest.mark.gpu
@@ -57,45 +58,6 @@ def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N, repl):
         check(r["mean"], r["var"], r["alpha"], float(r["logdet"]), ref, mr, vr)
     # every rank returns the same replicated result
     assert np.array_equal(res[0]["mean"], res[-1]["mean"]) and np.array_equal(res[0]["var"], res[-1]["var"])
-
-
-def c4_checks(res, N, M, one=None):
-    """SURVEY.md §8(d) checks for the C4 code path (no full oracle exists at its real size):
-    residual of K alpha = y on 1024 random rows (rows of K regenerated by the oracle kernel),
-    the train-point identity mean_i = y_i - sn2 alpha_i, 0 < var < sf2, every rank returns the same
-    numbers, and — where the problem fits one GPU — agreement with the unsharded path."""
-    sf2, sn2 = 1.5, 1e-2
-    X, y, Xs = synthetic_problem(N, 3, M, seed=12345)
-    r0 = res[0]
-    rows = r0["rows"]
-    assert all(int(r["info"]) == 0 for r in res)
-    for r in res[1:]:
-        assert np.array_equal(r["mean"], r0["mean"]) and np.array_equal(r["var"], r0["var"])
-        assert np.array_equal(r["alpha"], r0["alpha"])
-    alpha = r0["alpha"]
-    Kr = kernel_matrix(X[rows], X, "matern52", 0.25, sf2)
-    Kr[np.arange(len(rows)), rows] += sn2
-    resid = np.abs(Kr @ alpha - y[rows]).max()
-    assert resid <= 1e-8 * np.abs(y).max(), resid
-    assert np.max(np.abs(r0["mean_t"] - (y[rows] - sn2 * alpha[rows]))) <= 1e-8
-    assert np.all(r0["var_t"] > 0) and np.all(r0["var_t"] < sn2)
-    assert np.all(np.isfinite(r0["mean"])) and np.all(r0["var"] > 0) and np.all(r0["var"] < sf2)
-    Ks = kernel_matrix(Xs[:256], X, "matern52", 0.25, sf2)       # mean through an independent route
-    assert np.max(np.abs(Ks @ alpha - r0["mean"][:256])) <= 1e-9 * max(1.0, np.abs(r0["mean"]).max())
-    if one is not None:
-        m1, v1, a1, ld1 = one
-        assert np.max(np.abs(r0["mean"] - m1)) <= 1e-10 * np.abs(m1).max()
-        assert np.max(np.abs(r0["var"] - v1)) <= 1e-10 * sf2
-        assert np.max(np.abs(alpha - a1)) <= 1e-10 * np.abs(a1).max()
-        assert abs(float(r0["logdet"]) - ld1) <= 1e-12 * abs(ld1)
-    return resid
-
-
-def single_gpu_c4(N, M):
-    X, y, Xs = synthetic_problem(N, 3, M, seed=12345)
-    with GP("matern52", 0.25, 1.5, 1e-2, jitter=0.0, device=0) as gp:
-        m1, v1 = gp.fit(X, y).predict(Xs)
-        return m1, v1, gp.alpha_.copy(), gp.log_det_
 
 
 def test_c4_shape_on_one_gpu_world4(tmp_path):
