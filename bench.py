@@ -15,8 +15,10 @@ N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU.
       RCCL with one-panel look-ahead, value = (N+M) / max-over-ranks time, ``"scaling":
       "strong"``.  The sharded run lives in a CHILD process per rank (this process touches
       no GPU meanwhile) that writes a heartbeat and checks its posterior against the
-      single-GPU path on rank 0 (``shard_check``).  If a child fails, stalls or disagrees,
-      every rank falls back to --mode replicas and the JSON says so (``shard_fallback``).
+      single-GPU path on rank 0 (``shard_check``).  A child that fails, stalls or disagrees is a
+      FAILED run: rank 0 prints the JSON line with ``"value": null`` and the reason (with the
+      last heartbeat stage of the rank that noticed), and every rank exits non-zero.  Nothing is
+      substituted for the graded number.
   --mode shard: the sharded run in-process (what the child executes).
       ``--workload C4`` = N=262144, d=3, Matern-5/2 (needs 8 GPUs; no single-GPU check).
   --mode replicas: every rank runs its own replica of the workload (independent GPs, e.g.
@@ -29,7 +31,9 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                  summed over the launches of the timed steps (library events on the
                  library's stream, GPX_FLAG_PROFILE)
   cpu_baseline — the NumPy/SciPy oracle (oracle/gp_oracle.py) timed on this host's cores
-                 on a bounded sample (N=24576, same generator, ~20 s), rank 0, N=1 only
+                 on a bounded sample (N=24576, same generator, ~20 s), rank 0, N=1 only; BLAS
+                 threads = the CPUs this process may use (affinity and cgroup quota), and
+                 ``cores`` is exactly that thread count
 """
 from __future__ import annotations
 
@@ -89,41 +93,83 @@ def pmc_traffic():
     return (2.0 * fetch + write) * 1024.0, os.path.basename(files[-1])
 
 
-def cpu_baseline(n_sample=24576):
-    """Oracle fit+predict on the host cores, bounded sample (about 10-30 s)."""
-    import numpy as np
-    from oracle.gp_oracle import OracleGP
-    nthreads = None
-    try:
-        from threadpoolctl import threadpool_info
-        info = threadpool_info()
-        blas = [f"{p.get('internal_api')}:{p.get('num_threads')}" for p in info]
-        nthreads = max((int(p.get("num_threads") or 0) for p in info), default=0) or None
+def cpu_budget():
+    """CPUs this process may actually use: min(scheduler affinity, cgroup CPU quota)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:                                        # cgroup v2
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(p)
     except Exception:
-        blas = []
+        try:                                    # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    return aff, quota, int(max(1, min(aff, quota if quota else aff)))
+
+
+def full_size_oracle_record():
+    """The one measured FULL-size oracle run (tools/full_oracle_c3.py writes it under profiles/)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_full_oracle_parity.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                rec = json.load(fh)
+            if "oracle_points_per_s" in rec:
+                return {"file": os.path.basename(f), "points_per_s": rec["oracle_points_per_s"],
+                        "seconds": rec.get("oracle_fit_predict_s"), "threads": rec.get("blas_threads")}
+        except Exception:
+            pass
+    return None
+
+
+def cpu_baseline(n_sample=24576):
+    """Oracle fit+predict on the host cores, bounded sample (about 10-30 s).
+
+    The BLAS pools are limited to the CPUs this process may really use (affinity, cgroup
+    quota): a pool larger than the quota — the default is 64 threads on this pool's hosts
+    whatever the box's share — leaves most workers spinning inside a throttled cgroup and the
+    LAPACK Cholesky crawls (round 1: 30 GF/s with 64 threads against 27 GF/s with one)."""
+    import numpy as np
+    from threadpoolctl import threadpool_info, threadpool_limits
+    from oracle.gp_oracle import OracleGP
+    aff, quota, usable = cpu_budget()
+    pools = threadpool_info()
+    blas_max = max((int(p.get("num_threads") or 1) for p in pools if p.get("user_api") == "blas"), default=1)
+    threads = max(1, min(usable, blas_max))
     X, y, Xs = synthetic(n_sample, DIM, M_TEST, 12345)
-    t0 = time.perf_counter()
-    gp = OracleGP(KERNEL, LENGTHSCALE, SF2, SN2, jitter=0.0).fit(X, y)
-    t1 = time.perf_counter()
-    gp.predict(Xs)
-    t2 = time.perf_counter()
+    with threadpool_limits(limits=threads, user_api="blas"):
+        t0 = time.perf_counter()
+        gp = OracleGP(KERNEL, LENGTHSCALE, SF2, SN2, jitter=0.0).fit(X, y)
+        t1 = time.perf_counter()
+        gp.predict(Xs)
+        t2 = time.perf_counter()
     tm = gp.timings_
     r = N_TRAIN / n_sample
     # extrapolate each phase to N=65536 by its algorithmic work
     est = (tm["kbuild"] * r ** 2 + tm["chol"] * r ** 3 + tm["solve"] * r ** 2
            + (tm["kstar"] + tm["mean"]) * r + (tm["trsm"] + tm["var"]) * r ** 2) * 1e-3
-    cores = nthreads or os.cpu_count() or 1      # the threads the BLAS actually runs (host has more CPUs)
+    chol_gf = n_sample ** 3 / 3.0 / (tm["chol"] * 1e-3) / 1e9
+    full = full_size_oracle_record()
     return {
-        "value": (n_sample + M_TEST) / (t2 - t0), "unit": "points/s", "cores": cores,
+        "value": (n_sample + M_TEST) / (t2 - t0), "unit": "points/s", "cores": threads,
         "kind": "port",
-        "sample": (f"oracle/gp_oracle.py (NumPy/SciPy, BLAS threads {blas}, host os.cpu_count()={os.cpu_count()}) full fit+predict at "
-                   f"N={n_sample} d={DIM} M={M_TEST} RBF fp64, same generator: fit {t1 - t0:.2f} s "
-                   f"(kbuild {tm['kbuild']:.0f} ms, chol {tm['chol']:.0f} ms, solve {tm['solve']:.0f} ms), "
-                   f"predict {t2 - t1:.2f} s; phase-wise extrapolation to N={N_TRAIN}: "
-                   f"{est:.0f} s/step = {(N_TRAIN + M_TEST) / est:.1f} points/s (a one-off FULL-size "
-                   f"oracle run on a pool host took 165 s = 422 points/s: "
-                   f"profiles/r01_c3_full_oracle_parity.json)"),
+        "sample": (f"oracle/gp_oracle.py (NumPy/SciPy) full fit+predict at N={n_sample} (NOT the workload's "
+                   f"N={N_TRAIN}) d={DIM} M={M_TEST} RBF fp64, same generator, {threads} BLAS threads: fit "
+                   f"{t1 - t0:.2f} s (kbuild {tm['kbuild']:.0f} ms, chol {tm['chol']:.0f} ms = {chol_gf:.0f} GF/s, "
+                   f"solve {tm['solve']:.0f} ms), predict {t2 - t1:.2f} s; EXTRAPOLATED phase-wise to the "
+                   f"workload N={N_TRAIN}: {est:.0f} s/step = {(N_TRAIN + M_TEST) / est:.1f} points/s"
+                   + (f"; measured full-size run ({full['file']}): {full['points_per_s']:.1f} points/s" if full else "")),
+        "host": {"os_cpu_count": os.cpu_count(), "affinity_cpus": aff, "cgroup_cpu_quota": quota,
+                 "blas_pools": [f"{p.get('internal_api')} {p.get('version')}: {p.get('num_threads')} threads by default"
+                                for p in pools if p.get("user_api") == "blas"],
+                 "blas_threads_used": threads},
         "extrapolated_points_per_s_at_workload": (N_TRAIN + M_TEST) / est,
+        "measured_full_size": full,
     }
 
 
@@ -138,7 +184,7 @@ def main():
     ap.add_argument("--mode", choices=["auto", "replicas", "shard"], default="auto")
     ap.add_argument("--heartbeat", default=None, help="(internal) progress file of a supervised sharded child")
     ap.add_argument("--stall-timeout", type=float, default=300.0,
-                    help="auto mode: seconds without child progress before the fallback")
+                    help="auto mode: seconds without child progress before the run counts as failed")
     ap.add_argument("--workload", choices=["C3", "C4"], default="C3")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank code on one GPU (host collectives)")
@@ -149,18 +195,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    fallback = None
     if args.mode == "auto":
         if world > 1:
-            fallback = supervise_sharded_child(args)
-            if fallback is None:
+            failure = supervise_sharded_child(args)
+            if failure is None:
                 return                      # the child printed the JSON line
-            # the children used the launcher's store; the fallback group brings up its own
-            # (rank 0 hosts it) so that no key of the dead group is ever read
-            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-            os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+            # The graded multi-GPU path failed.  Say so and stop: no replicas number takes the
+            # place of `value`, and the exit code is non-zero on every rank.
+            if int(os.environ.get("RANK", "0")) == 0:
+                print(json.dumps({
+                    "metric": "gp_fit_predict_points_per_sec", "value": None, "unit": "points/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                    "data": "synthetic",
+                    "config": {"workload": f"{args.workload}: exact GP fit+predict, row-block-cyclic shard over "
+                                           f"{world} gpus", "parallelism": f"shard over {world} gpus (FAILED)"},
+                    "failed": failure}), flush=True)
+            sys.exit(1)
         args.mode = "replicas"
-    run(args, fallback)
+    run(args)
 
 
 def beat(args, what):
@@ -173,20 +226,23 @@ def beat(args, what):
 def supervise_sharded_child(args):
     """Run ``--mode shard`` in a child process (exact PID kept), watch its heartbeat file and
     the node-wide failure flag.  Returns None when the child finished ("done" mark), else the
-    reason for the fallback.  Nothing here touches the GPU."""
+    reason it failed.  Nothing here touches the GPU."""
     import subprocess
     import tempfile
     rank = int(os.environ.get("RANK", "0"))
-    # all ranks of one launch share the launcher as parent: its pid makes the names unique per run
-    tag = f"gpx_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    # All ranks of one launch share the launcher as parent: its pid AND its start time (clock
+    # ticks since boot, /proc/<pid>/stat field 22) make the names unique per launch, so no rank
+    # ever has to delete a file it did not create (a flag written by a faster rank survives).
+    ppid = os.getppid()
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            born = f.read().rsplit(")", 1)[1].split()[19]
+    except Exception:
+        born = "0"
+    tag = f"gpx_bench_{os.environ.get('MASTER_PORT', '0')}_{ppid}_{born}"
     tmp = tempfile.gettempdir()
     hb = os.path.join(tmp, f"{tag}_hb{rank}")
     flag = os.path.join(tmp, f"{tag}_failed")
-    for f in (hb,) + ((flag,) if rank == 0 else ()):
-        try:
-            os.remove(f)
-        except OSError:
-            pass
     open(hb, "w").close()
     argv = [a for a in sys.argv[1:]]
     cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--mode", "shard", "--heartbeat", hb]
@@ -227,7 +283,7 @@ def supervise_sharded_child(args):
     if child.poll() is None:
         child.kill()                        # exact PID of the process started above
         child.wait()
-    print(f"[bench] {reason}; falling back to independent replicas", file=sys.stderr, flush=True)
+    print(f"[bench] sharded run FAILED: {reason}", file=sys.stderr, flush=True)
     time.sleep(3.0)                         # let the other ranks see the flag and reap their children
     try:
         with open(flag) as f:
@@ -237,7 +293,7 @@ def supervise_sharded_child(args):
     return reason
 
 
-def run(args, fallback=None):
+def run(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -283,7 +339,7 @@ def run(args, fallback=None):
     else:
         gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True)
     beat(args, "communicator + inputs")
-    inject = os.environ.get("GPX_BENCH_INJECT", "")     # rehearsal of the fallback: fail:R / hang:R
+    inject = os.environ.get("GPX_BENCH_INJECT", "")     # rehearsal of the failure path: fail:R / hang:R
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -320,6 +376,14 @@ def run(args, fallback=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ok = bool(torch.isfinite(mean).all().item() and (var > 0).all().item())
+    pcie_ms = None
+    if world == 1 and not shard:
+        # the same step with HOST NumPy arrays in and out (H2D of X, y, Xs and D2H of mean, var inside
+        # the clock): never `value`, stated once beside it
+        gp.fit(X, y).predict(Xs)
+        t1 = time.perf_counter()
+        gp.fit(X, y).predict(Xs)
+        pcie_ms = (time.perf_counter() - t1) * 1e3
     shard_check = None
     if shard and N <= 131072:
         # the sharded posterior against the single-GPU path on the same inputs (rank 0's GPU)
@@ -359,7 +423,8 @@ def run(args, fallback=None):
             "metric": "gp_fit_predict_points_per_sec",
             "value": (1 if shard else world) * (N + M) * steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "ms_per_step": elapsed / steps * 1e3, "pcie_inclusive_ms_per_step": pcie_ms,
+            "higher_is_better": True,
             "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: exact GP fit+predict, N={N} d={DIM} {kernel} fp64, "
@@ -367,10 +432,9 @@ def run(args, fallback=None):
                        "kernel": kernel, "block": args.block or (shard_block(N, world) if shard else 1024),
                        "parallelism": "1 gpu" if world == 1 else
                        (f"row-block-cyclic shard over {world} gpus ({'RCCL' if args.backend == 'nccl' else 'host collectives, rehearsal'})" if shard
-                        else f"{world} independent replicas" + (" (FALLBACK: the sharded run failed)" if fallback else ""))},
+                        else f"{world} independent replicas")},
             "outputs_finite": ok,
             "shard_check": shard_check,
-            "shard_fallback": fallback,
             "phases_ms": phases,
             "roofline": {
                 "kernel": "gemm_nt_kernel<128,LOWER> (trailing SYRK of the blocked Cholesky)",

@@ -175,6 +175,36 @@ class OracleGP:
                      - 0.5 * n * k * math.log(2.0 * math.pi))
 
 
+    def lml_gradient(self):
+        """d LML / d log(theta), theta = (lengthscale[0..n_ls), variance, noise): R&W eq. 5.9,
+        1/2 tr((alpha alpha^T - K^-1) dK/dtheta) summed over the target columns.  SURVEY.md
+        §8(f) row 1 ("hyper-parameter gradient hooks"); no counterpart in the reference."""
+        X = self.X_
+        n = len(X)
+        A = self.alpha_.reshape(n, -1)
+        k = A.shape[1]
+        Linv = solve_triangular(self.L_, np.eye(n), lower=True, check_finite=False)
+        W = A @ A.T - k * (Linv.T @ Linv)
+        ls = np.atleast_1d(np.asarray(self.lengthscale, dtype=np.float64))
+        Xs = X / ls
+        Kf = kernel_matrix(X, X, self.kernel, self.lengthscale, self.variance)
+        if self.kernel == "rbf":
+            Kd = Kf                                       # dK/dlog l_c = Kf * d_c^2
+        else:
+            s = SQRT5 * dst.cdist(Xs, Xs, "euclidean")    # dK/dlog l_c = sf2 (5/3)(1+s) e^-s d_c^2
+            Kd = self.variance * (5.0 / 3.0) * (1.0 + s) * np.exp(-s)
+        WKd = W * Kd
+        g_ls = np.empty(Xs.shape[1])
+        for c in range(Xs.shape[1]):
+            dc = Xs[:, c][:, None] - Xs[:, c][None, :]
+            g_ls[c] = 0.5 * np.sum(WKd * dc * dc)
+        if ls.size == 1:
+            g_ls = np.array([g_ls.sum()])
+        g_sf2 = 0.5 * np.sum(W * Kf)
+        g_sn2 = 0.5 * self.noise * np.trace(W)
+        return np.concatenate([g_ls, [g_sf2, g_sn2]])
+
+
 # -- synthetic workload of SURVEY.md §8(d) --------------------------------------
 def synthetic_problem(N, d, M, seed=12345):
     """Draw order X, Xs, noise — fixed by SURVEY.md §8(d)."""

@@ -73,6 +73,26 @@ def test_config_C2_n8192_full_oracle():
         assert abs(gp.log_det_ - ref.log_det_) <= 1e-9 * abs(ref.log_det_)
 
 
+@pytest.mark.parametrize("batch", [128, 256, 640])
+def test_predict_in_batches_is_identical(monkeypatch, batch):
+    """Query rows are independent: batches of GPX_PRED_BATCH rows through one V^T buffer give
+    the very same numbers as one pass (ragged last batch, mean-only route included)."""
+    X, y, Xs = synthetic_problem(1500, 3, 700, seed=21)
+    Y = np.stack([y, np.sin(3 * y)], axis=1)
+    with GP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0) as gp:
+        gp.fit(X, Y)
+        m1, v1 = gp.predict(Xs)
+        mo1 = gp.predict(Xs, return_var=False)
+        monkeypatch.setenv("GPX_PRED_BATCH", str(batch))
+        m2, v2 = gp.predict(Xs)
+        mo2 = gp.predict(Xs, return_var=False)
+    assert np.array_equal(m1, m2) and np.array_equal(v1, v2) and np.array_equal(mo1, mo2)
+    ref = OracleGP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, Y)
+    mr, vr = ref.predict(Xs)
+    for c in range(2):
+        assert_parity(m2[:, c], v2, mr[:, c], vr, 1.5)
+
+
 def test_multi_output_and_noise_flag():
     X, y, Xs = synthetic_problem(700, 3, 50, seed=11)
     Y = np.stack([y, np.cos(y), 2 * y - 1], axis=1)
@@ -169,6 +189,18 @@ def test_config_C3_n65536_properties():
         Ks = kernel_matrix(Xs[:256], X, "rbf", 0.25, sf2)
         assert np.max(np.abs(Ks @ alpha - mean[:256])) <= 1e-9 * max(1.0, np.abs(mean).max())
         print("C3 timings:", gp.timings_)
+        # M = 65536 query points at N = 65536: K* / V^T would be 34 GB in one piece; predict
+        # streams them in batches of 8192 rows through one 4.3 GB buffer.  Stated budget for
+        # the whole handle: factor 34.4 GB + panels 1.1 GB + V^T batch 4.3 GB + small < 42 GB.
+        import torch
+        Xbig = np.random.default_rng(2).uniform(0, 1, (65536, d))
+        Xbig[:M] = Xs
+        mb, vb = gp.predict(Xbig)
+        free, total = torch.cuda.mem_get_info(0)
+        assert total - free <= 42e9, f"{(total - free) / 1e9:.1f} GB in use"
+        assert np.array_equal(mb[:M], mean) and np.array_equal(vb[:M], var)   # same rows, batched or not
+        assert np.all(np.isfinite(mb)) and np.all(vb > 0) and np.all(vb < sf2)
+        print("M=65536 predict:", {k_: round(v_, 1) for k_, v_ in gp.timings_.items() if k_ in ("kstar", "trsm", "mean", "var", "predict_total")})
 
 
 def test_hyperparameter_optimisation_climbs_the_marginal_likelihood():

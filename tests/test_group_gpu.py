@@ -50,6 +50,26 @@ def test_devices_surface_matches_oracle(monkeypatch, ndev, kernel, nb, N, M, rep
         assert np.array_equal(m3, mean) and np.array_equal(v3, var)
 
 
+@pytest.mark.parametrize("repl", [0, 1])
+def test_group_predict_in_batches(monkeypatch, repl):
+    """Sharded predict with GPX_PRED_BATCH = 128: several batches, each with its own look-ahead
+    chain of per-block broadcasts in the distributed mode (repl 0)."""
+    monkeypatch.setenv("GPX_NB_SHARD", "128")
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", str(repl))
+    X, y, Xs = synthetic_problem(1200, 3, 700, seed=5)
+    ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0, devices=[0, 0, 0]) as gp:
+        m1, v1 = gp.fit(X, y).predict(Xs)
+        monkeypatch.setenv("GPX_PRED_BATCH", "128")
+        m2, v2 = gp.predict(Xs)
+        check(m2, v2, gp.alpha_, gp.log_det_, ref, mr, vr)
+        if repl == 0:      # same batches on every rank, same arithmetic per row
+            assert np.array_equal(m1, m2) and np.array_equal(v1, v2)
+        else:              # the split of the query points over the ranks differs from one pass: rows still independent
+            assert np.max(np.abs(m1 - m2)) <= 1e-12 and np.max(np.abs(v1 - v2)) <= 1e-12
+
+
 def test_devices_list_and_single_entry():
     X, y, Xs = synthetic_problem(900, 3, 40, seed=3)
     ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)

@@ -98,3 +98,36 @@ def test_linear_algebra_pieces():
     A = rng.standard_normal((32, 64))
     X = trsm_right_lower_trans(A, L)
     assert np.allclose(X @ L.T, A)
+
+
+@pytest.mark.parametrize("name", ["G1", "G2"])
+def test_oracle_lml_gradient_matches_golden_and_sklearn(golden_dir, name):
+    """d LML / d log(lengthscale.., variance, noise): oracle vs its stored value and vs
+    scikit-learn's ``log_marginal_likelihood(theta, eval_gradient=True)`` (same fixture)."""
+    g = load(golden_dir, name)
+    gp = OracleGP(kernel=str(g["kernel"]), lengthscale=g["lengthscale"], variance=float(g["variance"]),
+                  noise=float(g["noise"]), jitter=0.0).fit(g["X"], g["y"])
+    grad = gp.lml_gradient()
+    scale = np.abs(g["sk_lml_grad"]).max()
+    assert np.max(np.abs(grad - g["lml_grad"])) <= 1e-9 * scale
+    assert np.max(np.abs(grad - g["sk_lml_grad"])) <= 1e-8 * scale
+
+
+@pytest.mark.parametrize("kernel,ls", [("rbf", 0.3), ("matern52", (0.3, 0.5)), ("rbf", (0.2, 0.4))])
+def test_oracle_lml_gradient_matches_central_differences(kernel, ls):
+    X, y, _ = synthetic_problem(150, 2, 1, seed=8)
+    Y = np.stack([y, np.cos(2 * y)], axis=1)          # two targets share the factor
+    sf2, sn2 = 1.3, 3e-2
+    ls = np.atleast_1d(np.asarray(ls, float))
+
+    def lml(v):
+        return OracleGP(kernel, np.exp(v[:ls.size]), np.exp(v[-2]), np.exp(v[-1]), jitter=0.0).fit(X, Y).log_marginal_likelihood()
+
+    v0 = np.log(np.concatenate([ls, [sf2, sn2]]))
+    grad = OracleGP(kernel, ls, sf2, sn2, jitter=0.0).fit(X, Y).lml_gradient()
+    h = 1e-5
+    for i in range(v0.size):
+        e = np.zeros_like(v0)
+        e[i] = h
+        fd = (lml(v0 + e) - lml(v0 - e)) / (2 * h)
+        assert abs(fd - grad[i]) <= 1e-6 * max(1.0, np.abs(grad).max()), (i, fd, grad[i])

@@ -22,10 +22,16 @@ def check(mean, var, alpha, logdet, ref, mr, vr, sf2=1.5):
 
 
 @pytest.mark.parametrize("N,M,nb,repl", [(1500, 130, 256, 0), (640, 64, 128, 0), (1500, 130, 256, 1),
-                                          (900, 1, 128, 1), (100, 5, 128, 0), (100, 5, 128, 1)])  # last two: ONE block
+                                          (900, 1, 128, 1), (100, 5, 128, 0), (100, 5, 128, 1),  # last two: ONE block
+                                          # library-chosen 1024-wide blocks at a size where the two streams (look-ahead
+                                          # panel + RCCL calls on st2, trailing update on st) really overlap on the card
+                                          (9000, 300, 0, 0), (9000, 300, 0, 1)])
 def test_sharded_schedule_single_rank_rccl(N, M, nb, repl, monkeypatch):
     """repl = 0: distributed solves (the C4-sized path); 1: whole factor kept on every rank."""
-    monkeypatch.setenv("GPX_NB_SHARD", str(nb))
+    if nb:
+        monkeypatch.setenv("GPX_NB_SHARD", str(nb))
+    else:
+        monkeypatch.delenv("GPX_NB_SHARD", raising=False)
     monkeypatch.setenv("GPX_SHARD_REPLICATE", str(repl))
     X, y, Xs = synthetic_problem(N, 3, M, seed=N)
     ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)

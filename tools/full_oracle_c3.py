@@ -2,8 +2,11 @@
 """One-off: FULL CPU oracle at the bench size (BASELINE.json configs[2]: N=65536, d=3, RBF,
 fp64, M=4096) against the HIP path — SURVEY.md §4/§8d "65536 (full oracle once; 34 GB host
 RAM)".  Same arithmetic as oracle/gp_oracle.py (cdist -> exp -> scipy cholesky ->
-solve_triangular), done in place to fit one 34.4 GB matrix.  Prints progress lines and one
-JSON line.   python tools/full_oracle_c3.py [--ntrain 65536]
+solve_triangular), done in place to fit one 34.4 GB matrix.  The BLAS pools are limited to the
+CPUs this process may use (bench.cpu_budget: affinity and cgroup quota).  Prints progress lines
+and one JSON line: parity of the HIP path at the bench size AND the measured full-size CPU
+baseline that bench.py quotes (oracle_points_per_s).
+    python tools/full_oracle_c3.py > profiles/r02_c3_full_oracle_parity.json
 """
 import argparse, json, os, sys, time
 import numpy as np
@@ -21,8 +24,13 @@ def main():
     a = ap.parse_args()
     from scipy.linalg import cholesky, solve_triangular
     from scipy.spatial import distance as dst
-    from bench import synthetic
+    from threadpoolctl import threadpool_info, threadpool_limits
+    from bench import cpu_budget, synthetic
     from gaussianprocesspathmodelling_amd import GP
+    aff, quota, usable = cpu_budget()
+    blas_max = max((int(p.get("num_threads") or 1) for p in threadpool_info() if p.get("user_api") == "blas"), default=1)
+    threads = max(1, min(usable, blas_max))
+    threadpool_limits(limits=threads, user_api="blas")
     N, M, ls, sf2, sn2 = a.ntrain, a.mtest, 0.25, 1.5, 1e-2
     X, y, Xs = synthetic(N, 3, M, 12345)
     t0 = time.time()
@@ -30,6 +38,7 @@ def main():
         mean, var = gp.fit(X, y).predict(Xs)
         alpha, logdet = gp.alpha_.copy(), gp.log_det_
     log(f"HIP path done in {time.time() - t0:.1f} s")
+    t_cpu = time.time()
     Xl = X / ls
     K = np.empty((N, N))
     step = 4096
@@ -45,7 +54,8 @@ def main():
     log("cholesky ...")
     t1 = time.time()
     L = cholesky(K, lower=True, overwrite_a=True, check_finite=False)
-    log(f"cholesky done in {time.time() - t1:.1f} s")
+    t_chol = time.time() - t1
+    log(f"cholesky done in {t_chol:.1f} s")
     z = solve_triangular(L, y, lower=True, check_finite=False)
     a_ref = solve_triangular(L, z, lower=True, trans="T", check_finite=False)
     ld_ref = 2.0 * float(np.sum(np.log(np.diag(L))))
@@ -57,12 +67,16 @@ def main():
     m_ref = Ks @ a_ref
     V = solve_triangular(L, Ks.T, lower=True, check_finite=False, overwrite_b=True)
     v_ref = sf2 - np.einsum("ij,ij->j", V, V)
+    cpu_s = time.time() - t_cpu
     rm = np.abs(mean - m_ref) / np.maximum(np.abs(m_ref), 1e-6)
     rv = np.abs(var - v_ref) / np.maximum(v_ref, 1e-6 * sf2)
     out = {"config": f"C3 full oracle: N={N} d=3 RBF fp64 M={M}", "mean_rel_max": float(rm.max()),
            "var_rel_max": float(rv.max()), "alpha_err_over_max": float(np.abs(alpha - a_ref).max() / np.abs(a_ref).max()),
            "logdet_rel": abs(logdet - ld_ref) / abs(ld_ref), "tolerance": 1e-6,
-           "pass": bool(rm.max() <= 1e-6 and rv.max() <= 1e-6), "oracle_seconds": time.time() - t0}
+           "pass": bool(rm.max() <= 1e-6 and rv.max() <= 1e-6),
+           "oracle_fit_predict_s": cpu_s, "oracle_points_per_s": (N + M) / cpu_s, "oracle_cholesky_s": t_chol,
+           "blas_threads": threads, "affinity_cpus": aff, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count(),
+           "command": "python tools/full_oracle_c3.py"}
     print(json.dumps(out), flush=True)
 
 
