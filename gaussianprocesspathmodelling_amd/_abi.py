@@ -32,7 +32,8 @@ class GpxTimings(C.Structure):
                 ("h2d", "kbuild", "chol", "solve", "logdet", "fit_total",
                  "kstar", "mean", "trsm", "var", "d2h", "predict_total",
                  "comm", "chol_diag", "chol_trsm", "chol_strip", "chol_syrk", "syrk_flops")] + \
-               [("syrk_launches", C.c_int64), ("kbuild_bytes", C.c_double)]
+               [("syrk_launches", C.c_int64), ("kbuild_bytes", C.c_double)] + \
+               [(n, C.c_double) for n in ("grad_trtri", "grad_trace", "grad_total")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -63,6 +64,7 @@ SIGNATURES = {
                           C.c_double, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_int64)]),
     "gpx_predict": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
     "gpx_get_alpha": (C.c_int, [_P, _P]),
+    "gpx_lml_grad": (C.c_int, [_P, _PD, _PD]),
     "gpx_logdet": (C.c_int, [_P, _PD]),
     "gpx_get_timings": (C.c_int, [_P, C.POINTER(GpxTimings)]),
     "gpx_comm_unique_id": (C.c_int, [_P]),

@@ -35,6 +35,12 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// No exception crosses the C ABI (include/gpx.h): every extern "C" entry point that can
+// allocate (std::string / std::vector / std::thread) is a function-try-block ending in this.
+#define GPX_CATCH_ALL                                  \
+  catch (const std::bad_alloc&) { return GPX_E_NOMEM; } \
+  catch (...) { return GPX_E_HIP; }
+
 constexpr int RHS_ROWS = 64;  // right-hand sides are padded to one 64-row MFMA slab
 
 struct Phase {
@@ -79,6 +85,7 @@ struct gpx_handle {
   void* alphaT = nullptr;  // alpha^T (64 x ld): AT (computed on demand from z^T) or YT (shard)
   bool alpha_ready = false;
   DevBuf AT;
+  DevBuf ZT, gpart;  // gpx_lml_grad: L^-T (Npad x ld) and the per-tile partial sums
   int nb_shard = 512;  // distribution block = panel width of the sharded factorisation (chosen per fit)
   int nb_shard_env = 0;  // GPX_NB_SHARD override (0: choose from N and the number of ranks)
   int64_t nloc = 0, ldy = 0;
@@ -383,8 +390,8 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
              const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter,
              int32_t mem_kind, int64_t* info) {
   const int64_t Npad = round_up(N, TILE);
-  const int64_t ld = Npad + LD_SKEW;
-  const int64_t ldp = h->nb + LD_SKEW;
+  const int64_t ld = Npad + ld_skew<T>();
+  const int64_t ldp = h->nb + ld_skew<T>();
   h->N = N; h->Npad = Npad; h->ld = ld; h->ldp = ldp; h->d = d; h->k = k; h->n_ls = n_ls;
   h->sf2 = sf2; h->sn2 = sn2; h->jitter = jitter;
   const bool profile = (h->cfg.flags & GPX_FLAG_PROFILE) != 0;
@@ -482,7 +489,7 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
   const int64_t N = h->N, Npad = h->Npad, ld = h->ld;
   const int d = h->d, k = h->k;
   const int64_t Mpad = round_up(M, TILE);
-  const int64_t ldm = Mpad + LD_SKEW;
+  const int64_t ldm = Mpad + ld_skew<T>();
   const int64_t MB = pred_batch_rows(h, Mpad, (size_t)ld * sizeof(T), true);
   gpx_timings& tm = h->tm;
   int rc;
@@ -550,6 +557,86 @@ int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var
   return GPX_OK;
 }
 
+// ZT (n x n, ld; the identity on entry) <- ZT * L^-T = L^-T, the forward substitution of
+// solve_fwd_enqueue restricted to the rows that are not structurally zero: row r of ZT is zero
+// left of column r, so column block [o, o+nb) only involves rows [0, o+nb).  N^3/3 flops,
+// same STRIP / REST look-ahead.
+int trtri_enqueue(gpx_handle* h, double* ZT, const double* L, int64_t ld, int64_t n, int nb,
+                  const double* Winv) {
+  hipStream_t s0 = h->st, s1 = h->st2;
+  launch_trsm_rlt<double>(ZT, ld, std::min<int64_t>(nb, n), L, ld, Winv, (int)std::min<int64_t>(nb, n), nullptr, 0, s0);
+  for (int64_t o = 0; o < n; o += nb) {
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    const int64_t t0 = o + nbp, ntrail = n - t0;
+    if (ntrail <= 0) break;
+    const int nbn = (int)std::min<int64_t>(nb, ntrail);
+    const int64_t nrest = ntrail - nbn;
+    const int64_t R = t0;  // rows [0, t0) of column block o are non-zero
+    const int tl = (R % 128 == 0 && nbn % 128 == 0 && nrest % 128 == 0) ? 128 : 64;
+    launch_gemm_nt<double>(tl, ZT + t0, ld, ZT + o, ld, L + t0 * ld + o, ld, R, nbn, nbp, 0, 0, s0);  // STRIP
+    hipEvent_t e_strip = next_event(h), e_blk = next_event(h);
+    if (!e_strip || !e_blk) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+    HIPCHK(h, hipEventRecord(e_strip, s0));
+    HIPCHK(h, hipStreamWaitEvent(s1, e_strip, 0));
+    // block column t0: rows [0, t0) just updated plus the identity rows [t0, t0 + nbn) of its own block
+    launch_trsm_rlt<double>(ZT + t0, ld, t0 + nbn, L + t0 * ld + t0, ld, Winv + (t0 / KB) * (KB * KB), nbn,
+                            nullptr, 0, s1);
+    HIPCHK(h, hipEventRecord(e_blk, s1));
+    if (nrest > 0)  // REST
+      launch_gemm_nt<double>(tl, ZT + t0 + nbn, ld, ZT + o, ld, L + (t0 + nbn) * ld + o, ld, R, nrest, nbp, 0, 0,
+                             s0);
+    HIPCHK(h, hipStreamWaitEvent(s0, e_blk, 0));
+  }
+  return GPX_OK;
+}
+
+int lml_grad_impl(gpx_handle* h, double* lml, double* grad) {
+  const int64_t N = h->N, Npad = h->Npad, ld = h->ld;
+  const int d = h->d, k = h->k, ntheta = h->n_ls + 2, ard = h->n_ls > 1;
+  gpx_timings& tm = h->tm;
+  tm.grad_trtri = tm.grad_trace = tm.grad_total = 0;
+  const int64_t s1n = kinv_trace_slots(Npad), s2n = alpha_quad_slots(Npad);
+  int rc;
+  if ((rc = ensure_alpha<double>(h))) return rc;
+  if ((rc = ensure(h, h->ZT, (size_t)Npad * ld * 8))) return rc;
+  if ((rc = ensure(h, h->gpart, (size_t)((s1n + s2n) * ntheta + 2 * ntheta + 1) * 8))) return rc;
+  double* ZT = (double*)h->ZT.p;
+  double* part1 = (double*)h->gpart.p;
+  double* part2 = part1 + s1n * ntheta;
+  double* outv = part2 + s2n * ntheta;  // [ntheta] K^-1 sums, [ntheta] alpha sums, [1] y . alpha
+  hipStream_t st = h->st;
+  {
+    PhaseScope total(h, &tm.grad_total);
+    {
+      PhaseScope ps(h, &tm.grad_trtri);
+      HIPCHK(h, hipMemsetAsync(ZT, 0, (size_t)Npad * ld * 8, st));
+      launch_set_diag_one(ZT, ld, Npad, st);
+      if ((rc = trtri_enqueue(h, ZT, (const double*)h->Lfac, ld, Npad, h->nb_pred, (const double*)h->Winv.p)))
+        return rc;
+    }
+    {
+      PhaseScope ps(h, &tm.grad_trace);
+      HIPCHK(h, hipMemsetAsync(part1, 0, (size_t)(s1n + s2n) * ntheta * 8, st));  // ragged-edge slots write nothing
+      launch_kinv_trace(h->cfg.kernel, ZT, ld, Npad, N, (const double*)h->Xs.p, d, ard, h->sf2, h->sn2, part1,
+                        ntheta, st);
+    }
+    launch_alpha_quad(h->cfg.kernel, (const double*)h->alphaT, ld, k, Npad, N, (const double*)h->Xs.p, d, ard,
+                      h->sf2, h->sn2, part2, ntheta, st);
+    launch_reduce_partials(part1, s1n, ntheta, 1.0, outv, st);
+    launch_reduce_partials(part2, s2n, ntheta, 1.0, outv + ntheta, st);
+    launch_dot_rhs((const double*)h->Y.p, (const double*)h->alphaT, ld, N, k, outv + 2 * ntheta, st);
+  }
+  double host[2 * 34 + 1];
+  HIPCHK(h, hipMemcpyAsync(host, outv, (size_t)(2 * ntheta + 1) * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, hipGetLastError());
+  collect_phases(h);
+  for (int t = 0; t < ntheta; ++t) grad[t] = 0.5 * (host[ntheta + t] - (double)k * host[t]);
+  *lml = -0.5 * host[2 * ntheta] - 0.5 * (double)k * h->logdet -
+         0.5 * (double)N * (double)k * 1.8378770664093454835606594728112;  // log(2 pi)
+  return GPX_OK;
+}
+
 template <typename T>
 int alpha_impl(gpx_handle* h, void* out) {
   int rc;
@@ -567,7 +654,7 @@ extern "C" {
 
 int gpx_abi_version(void) { return GPX_ABI_VERSION; }
 
-int gpx_device_count(int* count) {
+int gpx_device_count(int* count) try {
   if (!count) return GPX_E_ARG;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -577,10 +664,11 @@ int gpx_device_count(int* count) {
   *count = n;
   return GPX_OK;
 }
+GPX_CATCH_ALL
 
 const char* gpx_last_error(gpx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int gpx_create(gpx_handle** out, const gpx_config* cfg) {
+int gpx_create(gpx_handle** out, const gpx_config* cfg) try {
   if (!out || !cfg) return fail(nullptr, GPX_E_ARG, "gpx_create: null argument");
   *out = nullptr;
   if (cfg->kernel != GPX_KERNEL_RBF && cfg->kernel != GPX_KERNEL_MATERN52)
@@ -635,6 +723,7 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) {
   *out = h;
   return GPX_OK;
 }
+GPX_CATCH_ALL
 
 void gpx_destroy(gpx_handle* h) {
   if (!h) return;
@@ -649,7 +738,7 @@ void gpx_destroy(gpx_handle* h) {
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout, &h->G, &h->Pglob,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
-                    &h->GatherR, &h->outM, &h->outV})
+                    &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->gpart})
     release(*b);
   destroy_comm(h);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
@@ -660,7 +749,7 @@ void gpx_destroy(gpx_handle* h) {
 
 int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
             const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter,
-            int32_t mem_kind, int64_t* info) {
+            int32_t mem_kind, int64_t* info) try {
   if (!h) return GPX_E_ARG;
   if (!X || !y || !lengthscale || !info) return fail(h, GPX_E_ARG, "gpx_fit: null argument");
   if (N <= 0 || d <= 0 || d > 32) return fail(h, GPX_E_ARG, "gpx_fit: need N > 0 and 1 <= d <= 32");
@@ -686,8 +775,9 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
     return fit_impl<float>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
   return fit_impl<double>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
 }
+GPX_CATCH_ALL
 
-int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var, int32_t mem_kind) {
+int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var, int32_t mem_kind) try {
   if (!h) return GPX_E_ARG;
   if (!h->fitted) return fail(h, GPX_E_ARG, "gpx_predict: handle has no successful fit");
   if (!Xq || !mean || M <= 0) return fail(h, GPX_E_ARG, "gpx_predict: bad argument");
@@ -702,8 +792,9 @@ int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var,
   if (h->cfg.dtype == GPX_F32) return predict_impl<float>(h, Xq, M, mean, var, mem_kind);
   return predict_impl<double>(h, Xq, M, mean, var, mem_kind);
 }
+GPX_CATCH_ALL
 
-int gpx_get_alpha(gpx_handle* h, void* out) {
+int gpx_get_alpha(gpx_handle* h, void* out) try {
   if (!h) return GPX_E_ARG;
   if (!h->fitted || !out) return fail(h, GPX_E_ARG, "gpx_get_alpha: no fit or null output");
   if (h->group) {  // alpha is replicated (or solved on demand from the replicated factor): rank 0 has it
@@ -716,19 +807,36 @@ int gpx_get_alpha(gpx_handle* h, void* out) {
   if (h->cfg.dtype == GPX_F32) return alpha_impl<float>(h, out);
   return alpha_impl<double>(h, out);
 }
+GPX_CATCH_ALL
 
-int gpx_logdet(gpx_handle* h, double* out) {
+int gpx_lml_grad(gpx_handle* h, double* lml, double* grad) try {
+  if (!h) return GPX_E_ARG;
+  if (!h->fitted || !lml || !grad) return fail(h, GPX_E_ARG, "gpx_lml_grad: no fit or null output");
+  if (h->group || h->comm || h->cfg.world > 1)
+    return fail(h, GPX_E_UNSUPPORTED, "gpx_lml_grad: single-GPU handles only (the sharded factor is not inverted)");
+  if (h->cfg.dtype != GPX_F64) return fail(h, GPX_E_UNSUPPORTED, "gpx_lml_grad: fp64 handles only");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  h->err.clear();
+  h->phases.clear();
+  h->ev_used = 0;
+  return lml_grad_impl(h, lml, grad);
+}
+GPX_CATCH_ALL
+
+int gpx_logdet(gpx_handle* h, double* out) try {
   if (!h) return GPX_E_ARG;
   if (!h->fitted || !out) return fail(h, GPX_E_ARG, "gpx_logdet: no fit or null output");
   *out = h->group ? h->group->members[0]->logdet : h->logdet;
   return GPX_OK;
 }
+GPX_CATCH_ALL
 
-int gpx_get_timings(gpx_handle* h, gpx_timings* out) {
+int gpx_get_timings(gpx_handle* h, gpx_timings* out) try {
   if (!h || !out) return GPX_E_ARG;
   *out = h->group ? h->group->members[0]->tm : h->tm;  // a group reports rank 0's clocks
   return GPX_OK;
 }
+GPX_CATCH_ALL
 
 // ---- kernel unit-test entry points -------------------------------------------------------
 namespace {
@@ -763,7 +871,7 @@ struct Scratch {  // a throw-away handle-like context for the host-buffer entry 
 
 int gpx_kernel_matrix(int32_t kernel, const double* A, int64_t na, const double* B, int64_t nb_,
                       int32_t d, const double* lengthscale, int32_t n_ls, double sf2,
-                      double diag_add, double* K) {
+                      double diag_add, double* K) try {
   if (!A || !K || !lengthscale || na <= 0 || d <= 0 || d > 32 || (n_ls != 1 && n_ls != d))
     return GPX_E_ARG;
   if (kernel != GPX_KERNEL_RBF && kernel != GPX_KERNEL_MATERN52) return GPX_E_ARG;
@@ -804,8 +912,9 @@ done:
     if (p) (void)hipFree(p);
   return rc;
 }
+GPX_CATCH_ALL
 
-int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info) {
+int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info) try {
   if (!A || !info || n <= 0 || n % 64 != 0) return GPX_E_ARG;
   const int nb = block == 0 ? 1024 : block;
   if (nb % 128 != 0 || nb < 128) return GPX_E_ARG;
@@ -834,8 +943,9 @@ done:
     if (p) (void)hipFree(p);
   return rc;
 }
+GPX_CATCH_ALL
 
-int gpx_trsm(double* X, int64_t m, const double* L, int64_t nb) {
+int gpx_trsm(double* X, int64_t m, const double* L, int64_t nb) try {
   if (!X || !L || m <= 0 || nb <= 0 || m % 64 != 0 || nb % 64 != 0) return GPX_E_ARG;
   Scratch sc;
   if (!sc.ok) return GPX_E_HIP;
@@ -879,9 +989,10 @@ done:
     if (p) (void)hipFree(p);
   return rc;
 }
+GPX_CATCH_ALL
 
 int gpx_gemm_nt(double* C, int64_t m, int64_t n, const double* A, const double* B, int64_t k,
-                int32_t lower) {
+                int32_t lower) try {
   if (!C || !A || !B || m <= 0 || n <= 0 || k <= 0 || m % 64 || n % 64 || k % 16) return GPX_E_ARG;
   if (lower && m != n) return GPX_E_ARG;
   Scratch sc;
@@ -906,8 +1017,9 @@ done:
     if (p) (void)hipFree(p);
   return rc;
 }
+GPX_CATCH_ALL
 
-int gpx_mfma_probe(const double* A, const double* B, double* D) {
+int gpx_mfma_probe(const double* A, const double* B, double* D) try {
   if (!A || !B || !D) return GPX_E_ARG;
   Scratch sc;
   if (!sc.ok) return GPX_E_HIP;
@@ -925,9 +1037,10 @@ done:
   if (d) (void)hipFree(d);
   return rc;
 }
+GPX_CATCH_ALL
 
 int gpx_path_distance(const double* paths, int64_t P, const double* cents, int64_t C, int32_t L,
-                      double* D, int32_t mem_kind) {
+                      double* D, int32_t mem_kind) try {
   if (!paths || !cents || !D || P <= 0 || C <= 0 || L <= 0 || L > 64) return GPX_E_ARG;
   if (mem_kind != GPX_MEM_HOST && mem_kind != GPX_MEM_DEVICE) return GPX_E_ARG;
   Scratch sc;
@@ -954,8 +1067,9 @@ done:
     if (p) (void)hipFree(p);
   return rc;
 }
+GPX_CATCH_ALL
 
-int gpx_mfma_probe_f32(const float* A, const float* B, float* D) {
+int gpx_mfma_probe_f32(const float* A, const float* B, float* D) try {
   if (!A || !B || !D) return GPX_E_ARG;
   Scratch sc;
   if (!sc.ok) return GPX_E_HIP;
@@ -973,9 +1087,10 @@ done:
   if (d) (void)hipFree(d);
   return rc;
 }
+GPX_CATCH_ALL
 
 int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t tpb, int32_t c, int32_t* out,
-                       int64_t cap, int64_t* count) {
+                       int64_t cap, int64_t* count) try {
   if (!out || !count || tm <= 0 || cap <= 0 || (kind != 0 && kind != 1)) return GPX_E_ARG;
   if (kind == 1 && (tn <= 0 || P <= 0 || tpb <= 0 || c < 0)) return GPX_E_ARG;
   const int64_t n = debug_tile_map(kind, tm, tn, P, tpb, c, out, cap);
@@ -983,8 +1098,9 @@ int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t 
   *count = n;
   return GPX_OK;
 }
+GPX_CATCH_ALL
 
-int gpx_microbench(double* mfma_tflops, double* copy_gbs) {
+int gpx_microbench(double* mfma_tflops, double* copy_gbs) try {
   if (!mfma_tflops || !copy_gbs) return GPX_E_ARG;
   Scratch sc;
   if (!sc.ok) return GPX_E_HIP;
@@ -1029,5 +1145,6 @@ done:
     if (p) (void)hipFree(p);
   return rc;
 }
+GPX_CATCH_ALL
 
 }  // extern "C"

@@ -13,6 +13,7 @@
 // MFMA layouts (cdna_hip_programming.md §3), verified on hardware by gpx_mfma_probe:
 //   A lane l = A[l&15][l>>4],  B lane l = B[l>>4][l&15]   (both types)
 //   D reg r of lane l = D[(l>>4) + 4r][l&15]  for f64,   D[4(l>>4) + r][l&15]  for f32.
+#include <cstdio>
 #include <cstdlib>
 
 #include "gpx_internal.h"
@@ -439,6 +440,14 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
 // T makes a round trip through the slab's own global tile (L2-resident) so both
 // products run on the same tile engine; a slab is private to its workgroup, so the
 // only ordering needed is the workgroup barrier.
+// MEMORY-ORDERING INVARIANT: store_tile<MODE 0> updates T with no-return atomics that execute at
+// L2, and the LDS-DMA loads that read it back go through this CU's L1, which those atomics do
+// not refresh.  The read is fresh only because no 128-byte line of the tile can be in the L1
+// already: (i) every row of X starts on a 128-byte boundary and the tile's columns start at a
+// multiple of 64 elements, so no line straddles the tile's left edge (ld_skew, gpx_internal.h;
+// checked by the launcher), and (ii) the loads issued earlier in the walk touch only columns
+// < 64 jb of this slab, and nothing else of X.  The final result of block jb is written with
+// plain stores AFTER the read and never loaded by this workgroup again.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void trsm_rlt_kernel(T* X, int64_t ldx, const T* L, int64_t ldl,
                                                           const T* Winv, int nbq, T* P, int64_t ldp) {
@@ -529,6 +538,13 @@ void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipSt
 template <typename T>
 void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, const T* Winv, int nb,
                      T* P, int64_t ldp, hipStream_t st) {
+  // the kernel's L1 invariant (see trsm_rlt_kernel): 128-byte aligned rows of X.  Every caller
+  // builds ldx from ld_skew<T>(); a violation is a programming error in this library, caught
+  // here before a silently stale read can happen.
+  if (((uintptr_t)X | (uintptr_t)(ldx * (int64_t)sizeof(T))) % 128 != 0) {
+    fprintf(stderr, "libgpx: launch_trsm_rlt: X rows not 128-byte aligned (ldx = %lld)\n", (long long)ldx);
+    return;
+  }
   hipLaunchKernelGGL(trsm_rlt_kernel<T>, dim3((unsigned)(rows / 64)), dim3(256), 0, st, X, ldx, L, ldl,
                      Winv, nb / 64, P, ldp);
 }

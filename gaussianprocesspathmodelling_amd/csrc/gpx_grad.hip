@@ -119,6 +119,10 @@ __global__ __launch_bounds__(256, 2) void kinv_trace_kernel(const double* __rest
         const double t = v * kd;
         Sl += t * r2;
         acc[m][nn][r] = t;  // kept for the per-dimension pass (ARD)
+        // one element at a time: left alone, the scheduler interleaves all 64 evaluations of
+        // this fully unrolled nest (the accumulators must stay in registers) and spills hundreds
+        // of VGPRs; the epilogue is < 1 % of the tile's time either way
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   const double w = (ti == tj) ? 1.0 : 2.0;

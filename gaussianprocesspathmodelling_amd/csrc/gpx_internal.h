@@ -9,7 +9,20 @@ namespace gpx {
 
 constexpr int KB = 64;      // innermost Cholesky block (one-workgroup POTF2 + inverse)
 constexpr int TILE = 128;   // trailing-update tile; every padded dimension is a multiple
-constexpr int LD_SKEW = 16; // leading-dimension skew (elements) against power-of-two strides
+// Leading-dimension skew against power-of-two strides: ONE 128-byte line, so that every row of
+// every matrix starts on a 128-byte boundary (hipMalloc bases are 256-byte aligned; all padded
+// dimensions are multiples of 64 elements).  trsm_rlt_kernel DEPENDS on this: it round-trips a
+// 64x64 tile through global memory inside one workgroup — L2-side atomics, then LDS-DMA loads
+// through the CU's L1 — which is only coherent because no 128-byte line of the tile can already
+// sit in that L1: lines never straddle a tile edge (this alignment) and the earlier loads of the
+// walk touch only columns left of the tile.  Keep skew * sizeof(T) a multiple of 128.
+template <typename T>
+constexpr int ld_skew() {
+  return 128 / (int)sizeof(T);
+}
+constexpr int LD_SKEW = ld_skew<double>();  // fp64 buffers (16 elements)
+static_assert(ld_skew<double>() * sizeof(double) % 128 == 0 && ld_skew<float>() * sizeof(float) % 128 == 0,
+              "row starts must stay 128-byte aligned (trsm_rlt_kernel's L1 invariant)");
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -82,6 +95,25 @@ void launch_mfma_loop(double* sink, int iters, int blocks, hipStream_t st);
 int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, int bc_c, int32_t* out,
                        int64_t cap);
 void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st);
+
+// ---- log-marginal-likelihood gradient (gpx_grad.hip, fp64) -------------------------------------
+// theta = (lengthscale[0..n_ls), sf2, sn2), ntheta = n_ls + 2, ard = n_ls > 1.  Both passes write
+// one partial per (tile slot, theta); reduce_partials sums them in a fixed order.
+int64_t kinv_trace_slots(int64_t npad);  // slots of the 128-tile triangular map
+int64_t alpha_quad_slots(int64_t npad);  // 64-tiles of the lower triangle
+void launch_set_diag_one(double* A, int64_t lda, int64_t n, hipStream_t st);
+// part[slot][t] = sum over the tile of (ZT ZT^T)_ij (dK/dlog theta_t)_ij, ZT = L^-T (npad x npad, ld)
+void launch_kinv_trace(int kernel, const double* ZT, int64_t ld, int64_t npad, int64_t n, const double* Xs, int d,
+                       int ard, double sf2, double sn2, double* part, int ntheta, hipStream_t st);
+// part[slot][t] = sum over the tile of (sum_c alpha_ic alpha_jc) (dK/dlog theta_t)_ij, alphaT (k x npad, ld)
+void launch_alpha_quad(int kernel, const double* alphaT, int64_t ld, int k, int64_t npad, int64_t n,
+                       const double* Xs, int d, int ard, double sf2, double sn2, double* part, int ntheta,
+                       hipStream_t st);
+void launch_reduce_partials(const double* part, int64_t ntile, int ntheta, double scale, double* out,
+                            hipStream_t st);
+// out[0] = sum_i sum_c y[i*k + c] * alphaT[c*ld + i]
+void launch_dot_rhs(const double* y, const double* alphaT, int64_t ld, int64_t n, int k, double* out,
+                    hipStream_t st);
 
 // ---- path distance (gpx_paths.hip) -----------------------------------------------------------
 // D (P, ldd)[p][c] = sum_i ||paths[p][i] - cents[c][i]||, paths (P, L, 2), cents (C <= 64, L <= 64, 2)

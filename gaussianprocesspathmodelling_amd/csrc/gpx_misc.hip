@@ -106,11 +106,19 @@ __global__ __launch_bounds__(256, 2) void mfma_loop_kernel(double* sink, int ite
   if (s == 12345.678) sink[0] = s;  // keep the loop alive
 }
 
+// streaming copy, 16 B per lane, four independent loads in flight per lane before the first store
 __global__ __launch_bounds__(256) void copy_kernel(const double2* __restrict__ src,
                                                   double2* __restrict__ dst, int64_t count2) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count2;
-       i += (int64_t)gridDim.x * 256)
-    dst[i] = src[i];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < count2; i += 4 * stride) {
+    const double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a;
+    dst[i + stride] = b;
+    dst[i + 2 * stride] = c;
+    dst[i + 3 * stride] = d;
+  }
+  for (; i < count2; i += stride) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void fix_diag_kernel(double* A, int64_t lda, int n, int nvalid,
@@ -301,7 +309,7 @@ void launch_mfma_loop(double* sink, int iters, int blocks, hipStream_t st) {
 }
 
 void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st) {
-  hipLaunchKernelGGL(copy_kernel, dim3(4096), dim3(256), 0, st, reinterpret_cast<const double2*>(src),
+  hipLaunchKernelGGL(copy_kernel, dim3(16384), dim3(256), 0, st, reinterpret_cast<const double2*>(src),
                      reinterpret_cast<double2*>(dst), count / 2);
 }
 

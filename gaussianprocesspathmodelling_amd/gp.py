@@ -285,17 +285,32 @@ class GP:
         return float(-0.5 * np.sum(Y * A) - 0.5 * k * self.log_det_
                      - 0.5 * n * k * np.log(2.0 * np.pi))
 
+    def lml_gradient(self):
+        """``(lml, grad)`` of the last ``fit``: the log marginal likelihood and its analytic
+        gradient w.r.t. the LOG hyper-parameters, ordered (lengthscale[0..n_ls), variance, noise)
+        — R&W eq. 5.9, 1/2 tr((alpha alpha^T - K^-1) dK/dtheta), computed on the GPU by
+        ``gpx_lml_grad`` (about two more factorisations' worth of MFMA work: L^-T, then K^-1
+        formed and consumed tile by tile, never stored).  fp64 single-GPU models."""
+        if not self._fitted:
+            raise RuntimeError("lml_gradient() before a successful fit()")
+        lml = C.c_double(0.0)
+        grad = np.empty(self.lengthscale.size + 2, dtype=np.float64)
+        self._check(self._lib.gpx_lml_grad(self._h, C.byref(lml), _abi.dptr(grad)))
+        return float(lml.value), grad
+
     def optimize(self, X, y, params=("lengthscale", "variance", "noise"), bounds=(1e-4, 1e4), maxiter=40,
-                 rel_step=1e-4):
+                 rel_step=1e-4, jac="analytic"):
         """Fit the hyper-parameters by maximising the log marginal likelihood (SURVEY.md §8f
         rank 1: the natural step after ``fit``; the reference has no counterpart).
 
         ``params`` chooses what moves ("lengthscale" moves every ARD entry); the search runs in
-        log-space with L-BFGS-B and forward-difference gradients.  Every evaluation is one
-        ``fit()`` on the GPU — the factorisation is the only O(N^3) term, an exact gradient would
-        need K^-1 itself.  Non-positive-definite trial points count as very bad, they do not
-        raise.  Leaves the model fitted at the best point found and returns scipy's result
-        (``.fun`` = minus the log marginal likelihood there)."""
+        log-space with L-BFGS-B.  ``jac="analytic"`` (default): every evaluation is one ``fit()``
+        plus one ``lml_gradient()`` on the GPU, about three factorisations' worth of work whatever
+        the number of parameters.  Models without the analytic gradient (float32, sharded)
+        fall back to ``jac="3-point"`` central differences: 2 p extra fits per gradient.
+        Non-positive-definite trial points count as very bad, they do not raise.  Leaves the
+        model fitted at the best point found and returns scipy's result (``.fun`` = minus the
+        log marginal likelihood there)."""
         from scipy.optimize import minimize
         names = [p for p in ("lengthscale", "variance", "noise") if p in params]
         if not names or len(names) != len(tuple(params)):
@@ -320,24 +335,37 @@ class GP:
                     i += 1
 
         best = {"f": np.inf, "v": pack()}
+        analytic = (jac == "analytic" and self.dtype == "float64" and self.world == 1
+                    and len(self.devices) <= 1 and self._host_comm is None)
+        # columns of the full gradient (lengthscale.., variance, noise) that move
+        cols = []
+        for p in names:
+            cols.extend(range(n_ls) if p == "lengthscale" else [n_ls + (0 if p == "variance" else 1)])
 
         def objective(v):
             unpack(v)
+            g = np.zeros(len(cols))
             try:
                 self.fit(X, y)
-                f = -self.log_marginal_likelihood(y)
+                if analytic:
+                    lml, full = self.lml_gradient()
+                    f, g = -lml, -full[cols]
+                else:
+                    f = -self.log_marginal_likelihood(y)
             except np.linalg.LinAlgError:
                 f = 1e300
-            if not np.isfinite(f):
-                f = 1e300
+            if not np.isfinite(f) or not np.all(np.isfinite(g)):
+                f, g = 1e300, np.zeros(len(cols))
             if f < best["f"]:
                 best["f"], best["v"] = f, np.array(v, copy=True)
-            return f
+            return (f, g) if analytic else f
 
         v0 = pack()
         lo, hi = np.log(bounds[0]), np.log(bounds[1])
-        res = minimize(objective, v0, method="L-BFGS-B", jac="2-point", bounds=[(lo, hi)] * v0.size,
-                       options={"maxiter": int(maxiter), "eps": float(rel_step)})
+        res = minimize(objective, v0, method="L-BFGS-B", jac=True if analytic else "3-point",
+                       bounds=[(lo, hi)] * v0.size,
+                       options={"maxiter": int(maxiter)} if analytic else
+                       {"maxiter": int(maxiter), "eps": float(rel_step)})
         unpack(best["v"])
         self.fit(X, y)
         res.x, res.fun = best["v"], best["f"]

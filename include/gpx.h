@@ -90,6 +90,7 @@ typedef struct gpx_timings {
   double syrk_flops;                       /* algorithmic flops of all SYRK launches: n(n+1) nb each */
   int64_t syrk_launches;
   double kbuild_bytes;                     /* algorithmic bytes of the kernel build */
+  double grad_trtri, grad_trace, grad_total; /* gpx_lml_grad: L^-T build, fused K^-1 trace pass, whole call */
 } gpx_timings;
 
 /* ---- lifecycle ------------------------------------------------------------- */
@@ -114,6 +115,14 @@ int gpx_predict(gpx_handle* h, const void* Xs, int64_t M, void* mean, void* var,
                 int32_t mem_kind);
 
 int gpx_get_alpha(gpx_handle* h, void* out /* (N,k) host */);
+/* Log marginal likelihood of the last fit and its gradient w.r.t. the LOG hyper-parameters —
+ * SURVEY.md §8(f) row 1 ("log marginal likelihood + hyper-parameter gradient hooks"; no anchor
+ * in GPmap.py):  *lml = -1/2 sum_c y_c^T alpha_c - k/2 log|K| - N k/2 log 2 pi,
+ * grad[0..n_ls) = d lml / d log lengthscale, grad[n_ls] = d / d log sf2, grad[n_ls+1] = d / d log sn2
+ * (n_ls as passed to gpx_fit).  Costs about two more factorisations' worth of MFMA work
+ * (L^-T, then K^-1 = L^-T L^-1 consumed tile by tile as it is formed) and one extra N x N
+ * buffer; K^-1 itself is never stored.  fp64, single-GPU handles. */
+int gpx_lml_grad(gpx_handle* h, double* lml, double* grad);
 int gpx_logdet(gpx_handle* h, double* out);
 int gpx_get_timings(gpx_handle* h, gpx_timings* out);
 

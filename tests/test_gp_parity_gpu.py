@@ -203,10 +203,76 @@ def test_config_C3_n65536_properties():
         print("M=65536 predict:", {k_: round(v_, 1) for k_, v_ in gp.timings_.items() if k_ in ("kstar", "trsm", "mean", "var", "predict_total")})
 
 
+@pytest.mark.parametrize("name", ["G1", "G2", "G3"])
+def test_lml_gradient_matches_golden_fixtures(golden_dir, name):
+    """gpx_lml_grad against the gradient fixtures: the oracle's R&W eq. 5.9 value and
+    scikit-learn's ``log_marginal_likelihood(theta, eval_gradient=True)`` for the same inputs
+    (oracle/make_golden.py).  RBF scalar, Matern-5/2 scalar, RBF ARD."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    with GP(kernel=str(z["kernel"]), lengthscale=z["lengthscale"], variance=float(z["variance"]),
+            noise=float(z["noise"]), jitter=0.0) as gp:
+        gp.fit(z["X"], z["y"])
+        lml, grad = gp.lml_gradient()
+        assert abs(lml - float(z["lml"])) <= 1e-9 * abs(float(z["lml"]))
+        scale = np.abs(z["sk_lml_grad"]).max()
+        assert np.max(np.abs(grad - z["lml_grad"])) <= 1e-8 * scale, (grad, z["lml_grad"])
+        assert np.max(np.abs(grad - z["sk_lml_grad"])) <= 1e-8 * scale
+        lml2, grad2 = gp.lml_gradient()                     # deterministic: fixed-order reductions
+        assert lml2 == lml and np.array_equal(grad, grad2)
+        mean, var = gp.predict(z["Xs"])                      # the factor is untouched by the gradient
+        assert_parity(mean, var, z["mean"], z["var"], float(z["variance"]))
+
+
+@pytest.mark.parametrize("N,d,k,kernel,ls,block", [
+    (1000, 3, 1, "matern52", (0.3, 0.2, 0.25), 0),     # ragged N: padded rows must not contribute
+    (700, 2, 3, "rbf", 0.3, 0),                        # three targets share K^-1
+    (2300, 3, 2, "rbf", (0.3, 0.2, 0.25), 256),        # several 1024-blocks of the L^-T look-ahead chain
+    (300, 7, 1, "matern52", (1.0, 0.8, 1.2, 0.9, 1.1, 1.0, 0.7), 0),   # generic-d epilogue
+    (129, 1, 1, "rbf", 0.4, 0),
+])
+def test_lml_gradient_vs_oracle(N, d, k, kernel, ls, block):
+    X, y, _ = synthetic_problem(N, d, 1, seed=N)
+    Y = y if k == 1 else np.stack([np.cos(c * y) + 0.3 * c for c in range(k)], axis=1)
+    ref = OracleGP(kernel, ls, 1.3, 2e-2, jitter=0.0).fit(X, Y)
+    want = ref.lml_gradient()
+    with GP(kernel, ls, 1.3, 2e-2, jitter=0.0, block=block) as gp:
+        lml, grad = gp.fit(X, Y).lml_gradient()
+    assert abs(lml - ref.log_marginal_likelihood()) <= 1e-9 * abs(ref.log_marginal_likelihood())
+    assert np.max(np.abs(grad - want)) <= 1e-8 * np.abs(want).max(), (grad, want)
+
+
+def test_lml_gradient_at_scale_against_central_differences():
+    """N = 16384: no CPU oracle for K^-1 at this size in the suite; the analytic gradient must
+    match central differences of the GPU's own log marginal likelihood, and cost about two
+    fits — not one fit per parameter."""
+    N = 16384
+    X, y, _ = synthetic_problem(N, 3, 1)
+    ls, sf2, sn2 = np.array([0.3, 0.2, 0.25]), 1.5, 1e-2
+    with GP("rbf", ls, sf2, sn2, jitter=0.0) as gp:
+        gp.fit(X, y)
+        lml, grad = gp.lml_gradient()
+        tm = gp.timings_
+        assert abs(lml - gp.log_marginal_likelihood(y)) <= 1e-10 * abs(lml)
+    h = 1e-4
+    v0 = np.log(np.concatenate([ls, [sf2, sn2]]))
+    for i in range(5):
+        f = []
+        for sgn in (+1, -1):
+            v = v0.copy()
+            v[i] += sgn * h
+            with GP("rbf", np.exp(v[:3]), float(np.exp(v[3])), float(np.exp(v[4])), jitter=0.0) as g2:
+                f.append(g2.fit(X, y).log_marginal_likelihood(y))
+        fd = (f[0] - f[1]) / (2 * h)
+        assert abs(fd - grad[i]) <= 2e-5 * np.abs(grad).max(), (i, fd, grad[i])
+    print(f"N={N}: fit {tm['fit_total']:.1f} ms, gradient {tm['grad_total']:.1f} ms "
+          f"(L^-T {tm['grad_trtri']:.1f}, fused K^-1 trace {tm['grad_trace']:.1f})")
+
+
 def test_hyperparameter_optimisation_climbs_the_marginal_likelihood():
-    """§8(f) rank 1: L-BFGS-B over log-hyper-parameters, every evaluation one GPU fit.  The
-    likelihood it reports must be the oracle's at the same point, must not be below the start,
-    and must reach the neighbourhood of the generating parameters' likelihood."""
+    """§8(f) rank 1: L-BFGS-B over log-hyper-parameters with the analytic gradient, every
+    evaluation one GPU fit + one gpx_lml_grad.  The likelihood it reports must be the oracle's at
+    the same point, must not be below the start, and must reach the neighbourhood of the
+    generating parameters' likelihood."""
     rng = np.random.default_rng(3)
     N = 500
     X = rng.uniform(0, 1, (N, 2))
