@@ -65,6 +65,8 @@ struct gpx_handle {
   int nb_pred = 1024;  // block width of the variance TRSM
   hipStream_t st = nullptr;   // main stream
   hipStream_t st2 = nullptr;  // look-ahead (panel) stream, high priority
+  hipStream_t st3 = nullptr;  // side stream of the diagonal chain: in-block SYRKs, block inverses
+  hipStream_t st4 = nullptr;  // copy stream: solved panels / blocks back into their matrices
   std::string err;
   gpx_timings tm{};
   // fitted state
@@ -86,6 +88,9 @@ struct gpx_handle {
   bool alpha_ready = false;
   DevBuf AT;
   DevBuf ZT, gpart;  // gpx_lml_grad: L^-T (Npad x ld) and the per-tile partial sums
+  DevBuf Tsol;       // predict: compact solved blocks of V^T (2 x batch x (nb + skew))
+  DevBuf Wblk, Ublk; // explicit inverses of the nb x nb diagonal blocks of L ([Npad/nb][nb][nb]) + scratch
+  int nbw = 0;       // block width of Wblk (0: not built)
   int nb_shard = 512;  // distribution block = panel width of the sharded factorisation (chosen per fit)
   int nb_shard_env = 0;  // GPX_NB_SHARD override (0: choose from N and the number of ranks)
   int64_t nloc = 0, ldy = 0;
@@ -186,23 +191,99 @@ void collect_phases(gpx_handle* h) {
 // other P buffer) while the main stream runs the rest of update p; the two streams
 // touch disjoint columns of A.
 
-// diagonal block [o, o+nbp) on stream s
+// Explicit inverses W_p = L_pp^-1 of the nb x nb diagonal blocks, built BESIDE the factorisation
+// of each block on the auxiliary stream: with them a panel solve X <- X L_pp^-T is ONE dense
+// product X W_p^T on the MFMA tile engine instead of 64-row slabs each walking the nb/64 column
+// blocks in sequence (a latency chain of ~0.7 ms per panel whatever the number of rows — the
+// largest single item of a small-N fit: BASELINE.json configs[1]).
 template <typename T>
-void diag_enqueue(T* A, int64_t ld, int64_t o, int nbp, T* Winv, int* info, int64_t gidx0,
-                  hipStream_t s) {
-  for (int q = 0; q < nbp / KB; ++q) {
+struct InvWork {
+  T* W = nullptr;   // [n / nbw][nbw][nbw], row-major, lower triangular (strictly upper part zero)
+  T* U = nullptr;   // scratch: (L_pp^-1)^T of the block in flight, [nbw][ldu]
+  int64_t ldu = 0;
+  int nbw = 0;
+  hipStream_t aux = nullptr;
+  hipEvent_t ready = nullptr;  // recorded on aux when the inverse of the last enqueued block is complete
+};
+
+// diagonal block [o, o+nbp) on stream s.  iw != null: after the POTF2 of every 64-column step the
+// auxiliary stream extends the block's inverse by one column block of U / row block of W
+// (launch_inv_extend) — one event per step, nothing on the critical chain.
+template <typename T>
+int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, int* info, int64_t gidx0,
+                 hipStream_t s, InvWork<T>* iw = nullptr) {
+  T* Wp = nullptr;
+  if (iw) {
+    Wp = iw->W + (o / iw->nbw) * (int64_t)iw->nbw * iw->nbw;
+    HIPCHK(h, hipMemsetAsync(iw->U, 0, (size_t)iw->nbw * iw->ldu * sizeof(T), iw->aux));
+    launch_set_diag_one_t<T>(iw->U, iw->ldu, nbp, iw->aux);
+    HIPCHK(h, hipMemsetAsync(Wp, 0, (size_t)iw->nbw * iw->nbw * sizeof(T), iw->aux));
+  }
+  // The serial chain — POTF2, solve of the 64 columns below, SYRK inside the block — stays on ONE
+  // stream: moving the SYRK to a side stream (so that it would run beside the next POTF2) made
+  // the chain 40 % LONGER (measured at N = 8192: 49 -> 73 us per step), because every cross-stream
+  // event wait costs more than the 6 us launch it hides.  The inverse extension only ever waits
+  // FOR the chain (never the other way round), one event per step: batching the events four steps
+  // at a time saved 0.3 ms of chain at N = 8192 but let the inverse lag behind the block's last
+  // POTF2, and the panel solve waiting for it lost 0.7 ms.
+  const int nq = nbp / KB;
+  for (int q = 0; q < nq; ++q) {
     const int64_t oq = o + (int64_t)q * KB;
     T* Aqq = A + oq * ld + oq;
     T* Wq = Winv + (oq / KB) * (KB * KB);
-    launch_potf2_64(Aqq, ld, Wq, gidx0 + oq, info, s);
+    launch_potf2_64<T>(Aqq, ld, Wq, gidx0 + oq, info, s);
     const int64_t rem = o + nbp - (oq + KB);
     if (rem > 0) {
       T* panel = A + (oq + KB) * ld + oq;
       launch_trsm_rlt<T>(panel, ld, rem, Aqq, ld, Wq, KB, nullptr, 0, s);
-      launch_gemm_nt<T>(64, A + (oq + KB) * ld + (oq + KB), ld, panel, ld, panel, ld, rem, rem, KB, 1,
-                     0, s);
+      launch_gemm_nt<T>(64, A + (oq + KB) * ld + (oq + KB), ld, panel, ld, panel, ld, rem, rem, KB, 1, 0, s);
+    }
+    if (iw) {  // column block q of the inverse
+      hipEvent_t e = next_event(h);
+      if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (block inverse)");
+      HIPCHK(h, hipEventRecord(e, s));
+      HIPCHK(h, hipStreamWaitEvent(iw->aux, e, 0));
+      launch_inv_extend<T>(iw->U, iw->ldu, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), q, q + 1, Wp, iw->nbw,
+                           iw->aux);
     }
   }
+  if (iw) {
+    iw->ready = next_event(h);
+    if (!iw->ready) return fail(h, GPX_E_HIP, "hipEventCreate failed (block inverse)");
+    HIPCHK(h, hipEventRecord(iw->ready, iw->aux));
+  }
+  return GPX_OK;
+}
+
+// Panel solve below diagonal block [o, o+nbp): P (rows x nbp, ldp) = A[t.., o..] * L_pp^-T, also
+// stored back into A.  With the block inverse: two dense products (main rows / bordered rows) into
+// P on stream s, and the copy back into A on the auxiliary stream (nobody reads the panel from A
+// before the factorisation is over: the trailing updates read P).  Without: the slab kernel.
+template <typename T>
+int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int64_t rows_main, int64_t nx,
+                        const T* Winv, T* P, int64_t ldp, hipStream_t s, InvWork<T>* iw) {
+  T* Apanel = A + (o + nbp) * ld + o;
+  const int64_t rows = rows_main + nx;
+  if (rows <= 0) return GPX_OK;
+  if (!iw) {
+    launch_trsm_rlt<T>(Apanel, ld, rows, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, P, ldp, s);
+    return GPX_OK;
+  }
+  const T* Wp = iw->W + (o / iw->nbw) * (int64_t)iw->nbw * iw->nbw;
+  HIPCHK(h, hipStreamWaitEvent(s, iw->ready, 0));
+  if (rows_main > 0)
+    launch_gemm_nt<T>((rows_main % 128 == 0 && nbp % 128 == 0) ? 128 : 64, P, ldp, Apanel, ld, Wp, iw->nbw,
+                      rows_main, nbp, nbp, 4, 1, s);
+  if (nx > 0)
+    launch_gemm_nt<T>(64, P + rows_main * ldp, ldp, Apanel + rows_main * ld, ld, Wp, iw->nbw, nx, nbp, nbp, 4, 1,
+                      s);
+  hipEvent_t e = next_event(h);
+  if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (panel copy)");
+  HIPCHK(h, hipEventRecord(e, s));
+  HIPCHK(h, hipStreamWaitEvent(h->st4, e, 0));
+  HIPCHK(h, hipMemcpy2DAsync(Apanel, (size_t)ld * sizeof(T), P, (size_t)ldp * sizeof(T), (size_t)nbp * sizeof(T),
+                             (size_t)rows, hipMemcpyDeviceToDevice, h->st4));
+  return GPX_OK;
 }
 
 // nx extra rows (0 or a multiple of 64) directly below row n-1 ride along through every
@@ -211,19 +292,21 @@ void diag_enqueue(T* A, int64_t ld, int64_t o, int nbp, T* Winv, int* info, int6
 // z^T = (L^-1 y)^T — the forward substitution costs no serial pass of its own.
 template <typename T>
 int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T* P0, T* P1,
-                 int64_t ldp, int* info, int64_t gidx0, bool profile, int64_t nx = 0) {
+                 int64_t ldp, int* info, int64_t gidx0, bool profile, int64_t nx = 0,
+                 InvWork<T>* iw = nullptr) {
   hipStream_t s0 = h->st, s1 = h->st2;
   T* Pbuf[2] = {P0, P1};
+  int rc;
   // prologue: panel 0 on the main stream
   {
     const int nb0 = (int)std::min<int64_t>(nb, n);
     {
       PhaseScope ps(h, &h->tm.chol_diag, profile);
-      diag_enqueue(A, ld, 0, nb0, Winv, info, gidx0, s0);
+      if ((rc = diag_enqueue(h, A, ld, 0, nb0, Winv, info, gidx0, s0, iw))) return rc;
     }
-    if (n - nb0 + nx > 0) {
+    {
       PhaseScope ps(h, &h->tm.chol_trsm, profile);
-      launch_trsm_rlt<T>(A + (int64_t)nb0 * ld, ld, n - nb0 + nx, A, ld, Winv, nb0, Pbuf[0], ldp, s0);
+      if ((rc = panel_solve_enqueue(h, A, ld, 0, nb0, n - nb0, nx, Winv, Pbuf[0], ldp, s0, iw))) return rc;
     }
   }
   int step = 0;
@@ -255,12 +338,11 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     {  // look-ahead stream: factor diagonal block p+1, solve panel p+1
       {
         PhaseScope ps(h, &h->tm.chol_diag, profile, s1);
-        diag_enqueue(A, ld, t0, nbn, Winv, info, gidx0, s1);
+        if ((rc = diag_enqueue(h, A, ld, t0, nbn, Winv, info, gidx0, s1, iw))) return rc;
       }
-      if (nrest + nx > 0) {
+      {
         PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
-        launch_trsm_rlt<T>(A + (t0 + nbn) * ld + t0, ld, nrest + nx, A + t0 * ld + t0, ld,
-                           Winv + (t0 / KB) * (KB * KB), nbn, Pn, ldp, s1);
+        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest, nx, Winv, Pn, ldp, s1, iw))) return rc;
       }
     }
     HIPCHK(h, hipEventRecord(e_panel, s1));
@@ -273,6 +355,14 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     }
     HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
   }
+  if (iw) {  // join the side and copy streams: the last inverse and every panel copy-back are in W / A
+    for (hipStream_t sj : {iw->aux, h->st4}) {
+      hipEvent_t e = next_event(h);
+      if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (join)");
+      HIPCHK(h, hipEventRecord(e, sj));
+      HIPCHK(h, hipStreamWaitEvent(s0, e, 0));
+    }
+  }
   return GPX_OK;
 }
 
@@ -282,8 +372,16 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
 // columns of block p+1) and the REST; the high-priority stream solves block p+1 while
 // the main stream runs the rest of update p (disjoint columns of XT).
 template <typename T>
+struct SolveWork {       // optional: explicit block inverses + two compact result buffers (rows x ldt)
+  const T* W = nullptr;
+  int nbw = 0;
+  T *T0 = nullptr, *T1 = nullptr;
+  int64_t ldt = 0;
+};
+
+template <typename T>
 int solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld, int64_t n, int nb,
-                      const T* Winv) {
+                      const T* Winv, const SolveWork<T>* wb = nullptr) {
   hipStream_t s0 = h->st, s1 = h->st2;
   const int tile = (rows % 128 == 0) ? 128 : 64;
   if (rows < 128 || !s1) {
@@ -298,26 +396,60 @@ int solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld
     }
     return GPX_OK;
   }
-  launch_trsm_rlt<T>(XT, ld, rows, L, ld, Winv, (int)std::min<int64_t>(nb, n), nullptr, 0, s0);
-  for (int64_t o = 0; o < n; o += nb) {
+  // With the explicit block inverses of the factorisation (h->Wblk, same block width) a block
+  // solve is one dense product into a compact buffer Ts (which then also serves as the A operand
+  // of the updates) instead of the slab kernel's serial walk; the copy back into XT runs on the
+  // auxiliary stream.
+  const bool dense = wb && wb->nbw == nb && wb->T0 && h->st4;
+  T* Ts[2] = {dense ? wb->T0 : nullptr, dense ? wb->T1 : nullptr};
+  hipEvent_t e_copy[2] = {nullptr, nullptr};
+  const int64_t ldt = dense ? wb->ldt : 0;
+  auto block_solve = [&](int64_t o, int nbp, int set, hipStream_t s) -> int {
+    if (!dense) {
+      launch_trsm_rlt<T>(XT + o, ld, rows, L + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, nullptr, 0, s);
+      return GPX_OK;
+    }
+    if (e_copy[set]) HIPCHK(h, hipStreamWaitEvent(s, e_copy[set], 0));  // Ts[set] is free again
+    launch_gemm_nt<T>((rows % 128 == 0 && nbp % 128 == 0) ? 128 : 64, Ts[set], ldt, XT + o, ld,
+                      wb->W + (o / nb) * (int64_t)nb * nb, nb, rows, nbp, nbp, 4, 1, s);
+    hipEvent_t e = next_event(h);
+    e_copy[set] = next_event(h);
+    if (!e || !e_copy[set]) return fail(h, GPX_E_HIP, "hipEventCreate failed (block solve)");
+    HIPCHK(h, hipEventRecord(e, s));
+    HIPCHK(h, hipStreamWaitEvent(h->st4, e, 0));
+    HIPCHK(h, hipMemcpy2DAsync(XT + o, (size_t)ld * sizeof(T), Ts[set], (size_t)ldt * sizeof(T),
+                               (size_t)nbp * sizeof(T), (size_t)rows, hipMemcpyDeviceToDevice, h->st4));
+    HIPCHK(h, hipEventRecord(e_copy[set], h->st4));
+    return GPX_OK;
+  };
+  int rc;
+  if ((rc = block_solve(0, (int)std::min<int64_t>(nb, n), 0, s0))) return rc;
+  int step = 0;
+  for (int64_t o = 0; o < n; o += nb, ++step) {
     const int nbp = (int)std::min<int64_t>(nb, n - o);
     const int64_t t0 = o + nbp, ntrail = n - t0;
     if (ntrail <= 0) break;
     const int nbn = (int)std::min<int64_t>(nb, ntrail);
     const int64_t nrest = ntrail - nbn;
     const int tl = (nbn % 128 == 0 && nrest % 128 == 0) ? tile : 64;
-    launch_gemm_nt<T>(tl, XT + t0, ld, XT + o, ld, L + t0 * ld + o, ld, rows, nbn, nbp, 0, 0, s0);  // STRIP
+    const int cur = step & 1;
+    const T* Ablk = dense ? Ts[cur] : XT + o;  // the solved block o (rows x nbp)
+    const int64_t lda = dense ? ldt : ld;
+    launch_gemm_nt<T>(tl, XT + t0, ld, Ablk, lda, L + t0 * ld + o, ld, rows, nbn, nbp, 0, 0, s0);  // STRIP
     hipEvent_t e_strip = next_event(h), e_panel = next_event(h);
     if (!e_strip || !e_panel) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
     HIPCHK(h, hipEventRecord(e_strip, s0));
     HIPCHK(h, hipStreamWaitEvent(s1, e_strip, 0));
-    launch_trsm_rlt<T>(XT + t0, ld, rows, L + t0 * ld + t0, ld, Winv + (t0 / KB) * (KB * KB), nbn, nullptr,
-                       0, s1);
+    if ((rc = block_solve(t0, nbn, cur ^ 1, s1))) return rc;
     HIPCHK(h, hipEventRecord(e_panel, s1));
     if (nrest > 0)  // REST
-      launch_gemm_nt<T>(tl, XT + t0 + nbn, ld, XT + o, ld, L + (t0 + nbn) * ld + o, ld, rows, nrest, nbp, 0,
-                        0, s0);
+      launch_gemm_nt<T>(tl, XT + t0 + nbn, ld, Ablk, lda, L + (t0 + nbn) * ld + o, ld, rows, nrest, nbp, 0, 0,
+                        s0);
     HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
+  }
+  if (dense) {  // every block is back in XT
+    for (int set = 0; set < 2; ++set)
+      if (e_copy[set]) HIPCHK(h, hipStreamWaitEvent(s0, e_copy[set], 0));
   }
   return GPX_OK;
 }
@@ -412,6 +544,17 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   if ((rc = ensure(h, h->P, (size_t)2 * (Npad + NX) * ldp * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->scalars, 64))) return rc;
   if ((rc = ensure(h, h->info, 64))) return rc;
+  const int64_t nblk = (Npad + h->nb - 1) / h->nb;
+  const int64_t ldu = h->nb + ld_skew<T>();
+  if ((rc = ensure(h, h->Wblk, (size_t)nblk * h->nb * h->nb * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->Ublk, (size_t)h->nb * ldu * sizeof(T)))) return rc;
+  InvWork<T> iw;
+  iw.W = (T*)h->Wblk.p;
+  iw.U = (T*)h->Ublk.p;
+  iw.ldu = ldu;
+  iw.nbw = h->nb;
+  iw.aux = h->st3;
+  h->nbw = 0;  // valid again once this fit has finished
 
   T* dK = (T*)h->K.p;
   h->Lfac = dK;
@@ -442,7 +585,7 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
       PhaseScope ps(h, &tm.chol);
       launch_pack_rhs<T>((const T*)h->Y.p, N, k, dYT, ld, Npad, (int)NX, h->st);
       if ((rc = chol_enqueue<T>(h, dK, ld, Npad, h->nb, (T*)h->Winv.p, (T*)h->P.p,
-                                (T*)h->P.p + (Npad + NX) * ldp, ldp, dInfo, 0, profile, NX)))
+                                (T*)h->P.p + (Npad + NX) * ldp, ldp, dInfo, 0, profile, NX, &iw)))
         return rc;
     }
     // The forward substitution happened inside the factorisation (bordered rows).  The
@@ -462,6 +605,7 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   collect_phases(h);
   *info = (hinfo == INT_MAX) ? 0 : (int64_t)hinfo;
   h->fitted = (*info == 0);
+  if (h->fitted) h->nbw = h->nb;
   return GPX_OK;
 }
 
@@ -499,6 +643,15 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
   if ((rc = ensure(h, h->MT, (size_t)RHS_ROWS * ldm * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->meanout, (size_t)M * k * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->var, (size_t)Mpad * sizeof(T)))) return rc;
+  SolveWork<T> sw;
+  if (want_var && h->nbw == h->nb_pred && !h->comm) {  // block inverses of this fit, same block width
+    sw.ldt = h->nbw + ld_skew<T>();
+    if ((rc = ensure(h, h->Tsol, (size_t)2 * MB * sw.ldt * sizeof(T)))) return rc;
+    sw.W = (const T*)h->Wblk.p;
+    sw.nbw = h->nbw;
+    sw.T0 = (T*)h->Tsol.p;
+    sw.T1 = sw.T0 + MB * sw.ldt;
+  }
   T* dVT = (T*)h->VT.p;
   const T* dK = (const T*)h->Lfac;
   const T* dWinv = (const T*)h->Winv.p;
@@ -520,7 +673,7 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
     }
     if (want_var) {
       PhaseScope ps(h, &tm.trsm);
-      if ((rc = solve_fwd_enqueue<T>(h, dVT, mp, dK, ld, Npad, h->nb_pred, dWinv))) return rc;
+      if ((rc = solve_fwd_enqueue<T>(h, dVT, mp, dK, ld, Npad, h->nb_pred, dWinv, sw.W ? &sw : nullptr))) return rc;
     }
     {  // with the variance: mean^T (64 x mp) = z^T (64 x Npad) * V   (mu = K* K^-1 y = V^T z);
        // mean only: alpha^T * K*^T
@@ -715,8 +868,11 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) try {
   if (hipSetDevice(device) != hipSuccess ||
       hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||
       hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithPriority(&h->st2, hipStreamNonBlocking, prio_hi) != hipSuccess) {
-    if (h->st) (void)hipStreamDestroy(h->st);
+      hipStreamCreateWithPriority(&h->st2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipStreamCreateWithPriority(&h->st3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->st4, hipStreamNonBlocking) != hipSuccess) {
+    for (hipStream_t sx : {h->st, h->st2, h->st3})
+      if (sx) (void)hipStreamDestroy(sx);
     delete h;
     return fail(nullptr, GPX_E_HIP, "gpx_create: hipSetDevice/hipStreamCreate failed");
   }
@@ -735,15 +891,19 @@ void gpx_destroy(gpx_handle* h) {
   (void)hipSetDevice(h->cfg.device);
   if (h->st) (void)hipStreamSynchronize(h->st);
   if (h->st2) (void)hipStreamSynchronize(h->st2);
+  if (h->st3) (void)hipStreamSynchronize(h->st3);
+  if (h->st4) (void)hipStreamSynchronize(h->st4);
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout, &h->G, &h->Pglob,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
-                    &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->gpart})
+                    &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->gpart, &h->Wblk, &h->Ublk, &h->Tsol})
     release(*b);
   destroy_comm(h);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->st) (void)hipStreamDestroy(h->st);
   if (h->st2) (void)hipStreamDestroy(h->st2);
+  if (h->st3) (void)hipStreamDestroy(h->st3);
+  if (h->st4) (void)hipStreamDestroy(h->st4);
   delete h;
 }
 
@@ -848,10 +1008,12 @@ struct Scratch {  // a throw-away handle-like context for the host-buffer entry 
     if (hipGetDevice(&dev) != hipSuccess) return;
     h.cfg.device = dev;
     ok = hipStreamCreateWithFlags(&h.st, hipStreamNonBlocking) == hipSuccess &&
-         hipStreamCreateWithFlags(&h.st2, hipStreamNonBlocking) == hipSuccess;
+         hipStreamCreateWithFlags(&h.st2, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&h.st3, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&h.st4, hipStreamNonBlocking) == hipSuccess;
   }
   ~Scratch() {
-    for (hipStream_t s : {h.st, h.st2})
+    for (hipStream_t s : {h.st, h.st2, h.st3, h.st4})
       if (s) {
         (void)hipStreamSynchronize(s);
         (void)hipStreamDestroy(s);
@@ -922,24 +1084,32 @@ int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info) try {
   if (!sc.ok) return GPX_E_HIP;
   hipStream_t st = sc.h.st;
   const int64_t ld = n + LD_SKEW, ldp = nb + LD_SKEW;
-  double *dA = nullptr, *dW = nullptr, *dP = nullptr;
+  double *dA = nullptr, *dW = nullptr, *dP = nullptr, *dWb = nullptr, *dUb = nullptr;
   int* dInfo = nullptr;
   int hinfo = INT_MAX;
   int rc = GPX_OK;
+  InvWork<double> iw;
   TCHK(hipMalloc(&dA, (size_t)n * ld * 8));
   TCHK(hipMalloc(&dW, (size_t)(n / 64) * 4096 * 8));
   TCHK(hipMalloc(&dP, (size_t)2 * n * ldp * 8));
   TCHK(hipMalloc(&dInfo, 64));
+  TCHK(hipMalloc(&dWb, (size_t)((n + nb - 1) / nb) * nb * nb * 8));
+  TCHK(hipMalloc(&dUb, (size_t)nb * ldp * 8));
+  iw.W = dWb;
+  iw.U = dUb;
+  iw.ldu = ldp;
+  iw.nbw = nb;
+  iw.aux = sc.h.st3;
   TCHK(hipMemcpy2DAsync(dA, (size_t)ld * 8, A, (size_t)n * 8, (size_t)n * 8, (size_t)n, hipMemcpyHostToDevice, st));
   TCHK(hipMemcpyAsync(dInfo, &hinfo, sizeof(int), hipMemcpyHostToDevice, st));
-  if ((rc = chol_enqueue(&sc.h, dA, ld, n, nb, dW, dP, dP + n * ldp, ldp, dInfo, 0, false))) goto done;
+  if ((rc = chol_enqueue(&sc.h, dA, ld, n, nb, dW, dP, dP + n * ldp, ldp, dInfo, 0, false, 0, &iw))) goto done;
   TCHK(hipMemcpy2DAsync(A, (size_t)n * 8, dA, (size_t)ld * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToHost, st));
   TCHK(hipMemcpyAsync(&hinfo, dInfo, sizeof(int), hipMemcpyDeviceToHost, st));
   TCHK(hipStreamSynchronize(st));
   TCHK(hipGetLastError());
   *info = (hinfo == INT_MAX) ? 0 : hinfo;
 done:
-  for (void* p : {(void*)dA, (void*)dW, (void*)dP, (void*)dInfo})
+  for (void* p : {(void*)dA, (void*)dW, (void*)dP, (void*)dInfo, (void*)dWb, (void*)dUb})
     if (p) (void)hipFree(p);
   return rc;
 }

@@ -130,10 +130,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
   const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
   int ti, tj;
-  if (!tile_coords<TRI>(lin, tiles_m, tiles_n, sh, mask_lower, bc, ti, tj)) return;
+  if (!tile_coords<TRI>(lin, tiles_m, tiles_n, sh, mask_lower & 3, bc, ti, tj)) return;
   typename Num<T>::v4 acc[BT / 32][BT / 32];
   zero_acc(acc);
   T* Ct = C + (int64_t)ti * BT * ldc + (int64_t)tj * BT;
+  // mask_lower bit 2: B is lower triangular (an explicit block inverse): rows of tile column tj
+  // are zero right of column (tj + 1) BT
+  if (mask_lower & 4) K = min(K, (tj + 1) * BT);
   gemm_tile_g<T, BT, BT>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc,
                          smem);
   // (a software-pipelined epilogue — strips of C prefetched / kept in flight — measured
@@ -264,6 +267,20 @@ constexpr int PLD = 66;
 constexpr int TLD = 34;
 constexpr int PW = 8;  // columns per factorisation step (a multiple of 4: one MFMA per 4)
 
+// Diagnostic build only (tools/potf2_stamps.py compiles its own copy with -DGPX_STAMPS): shader-clock
+// stamps of thread 0 at the phase boundaries of the POTF2 kernel.  Never in the shipped library.
+#ifdef GPX_STAMPS
+__device__ long long gpx_stamp_buf[64];
+#define GPX_STAMP(i)                                                  \
+  do {                                                                \
+    if (threadIdx.x == 0) gpx_stamp_buf[i] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define GPX_STAMP(i) \
+  do {               \
+  } while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_t lda,
                                                        T* __restrict__ Winv, int64_t gidx0,
@@ -279,12 +296,26 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
   const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const T zero = (T)0, one = (T)1;
-  for (int e = tid; e < 4096; e += 256) {
-    const int i = e >> 6, k = e & 63;
-    Wk[i * PLD + k] = (k <= i) ? A[(int64_t)i * lda + k] : zero;
-    Wi[i * PLD + k] = zero;
+  GPX_STAMP(0);
+  {
+    // all 16 loads of a thread in flight before the first LDS write: the tile comes from HBM /
+    // Infinity Cache (the trailing update's atomics leave nothing in L2), and one dependent
+    // load -> ds_write pair per iteration serialised 16 misses (18 k of the kernel's 62 k cycles)
+    T v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u, i = e >> 6, k = e & 63;
+      v[u] = (k <= i) ? A[(int64_t)i * lda + k] : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u, i = e >> 6, k = e & 63;
+      Wk[i * PLD + k] = v[u];
+      Wi[i * PLD + k] = zero;
+    }
   }
   __syncthreads();
+  GPX_STAMP(1);
 
   for (int j = 0; j < 64; j += PW) {
     // ---- phase A: PW x PW diagonal factor (redundant per thread, right-looking in
@@ -335,6 +366,7 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
       for (int k = 0; k < PW; ++k) PB[i * PW + k] = x[k];
     }
     __syncthreads();
+    GPX_STAMP(2 + 2 * (j / PW));
     // ---- phase B: commit the panel, rank-PW update of the trailing lower tiles
     if (tid < 64 && tid >= j) {
       T* row = Wk + tid * PLD + j;
@@ -362,6 +394,7 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
         }
       }
     __syncthreads();
+    GPX_STAMP(3 + 2 * (j / PW));
   }
 
   // ---- inverse, level 0: wave w inverts diagonal block w; lane c < 16 owns column c
@@ -426,11 +459,13 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
       Wi[(32 + tr * 16 + Num<T>::drow(l4, r)) * PLD + tc * 16 + l15] = -acc2[r];
   }
   __syncthreads();
+  GPX_STAMP(20);
   for (int e = tid; e < 4096; e += 256) {
     const int ii = e >> 6, k = e & 63;
     if (k <= ii) A[(int64_t)ii * lda + k] = Wk[ii * PLD + k];
     Winv[e] = Wi[ii * PLD + k];
   }
+  GPX_STAMP(21);
 }
 
 // ---- X <- X * L^-T (right, lower, transposed): ascending 64-column blocks --------------
@@ -448,19 +483,42 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
 // checked by the launcher), and (ii) the loads issued earlier in the walk touch only columns
 // < 64 jb of this slab, and nothing else of X.  The final result of block jb is written with
 // plain stores AFTER the read and never loaded by this workgroup again.
+// C^T -> Wt: element (r, c) of the wave-tiled 64x64 accumulator goes to Wt[c * ldw + r]
+template <typename T>
+__device__ __forceinline__ void store_tile_transposed(T* Wt, int64_t ldw, const typename Num<T>::v4 (&acc)[2][2],
+                                                      T sign) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l4 = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wr * 32 + m * 16 + Num<T>::drow(l4, r), col = wc * 32 + n * 16 + l15;
+        Wt[(int64_t)col * ldw + row] = sign * acc[m][n][r];
+      }
+}
+
+// Column blocks [jb_lo, jb_hi) only (the earlier ones must already be solved).  tri != 0: X is
+// block upper triangular (slab s is zero left of column block s — the inverse being built from
+// the identity), so slab s starts its contraction at column 64 s.  Wt != null: the solved block
+// is also written transposed, Wt[(64 jb + c) * ldw + 64 slab + r] = X[r][64 jb + c].
 template <typename T>
 __global__ __launch_bounds__(256, 2) void trsm_rlt_kernel(T* X, int64_t ldx, const T* L, int64_t ldl,
-                                                          const T* Winv, int nbq, T* P, int64_t ldp) {
+                                                          const T* Winv, int jb_lo, int jb_hi, T* P, int64_t ldp,
+                                                          int tri, T* Wt, int64_t ldw) {
   __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 64, 64>::SMEM_ELEMS];
   __builtin_amdgcn_s_setprio(2);  // panel solve is on the critical path of the look-ahead
   T* Xs = X + (int64_t)blockIdx.x * 64 * ldx;
   T* Ps = P ? P + (int64_t)blockIdx.x * 64 * ldp : nullptr;
+  const int k0 = tri ? (int)blockIdx.x * 64 : 0;
   typename Num<T>::v4 acc[2][2];
-  for (int jb = 0; jb < nbq; ++jb) {
+  for (int jb = jb_lo; jb < jb_hi; ++jb) {
     T* Xj = Xs + jb * 64;
-    if (jb > 0) {
+    if (jb * 64 > k0) {
       zero_acc(acc);
-      gemm_tile_g<T, 64, 64>(Xs, ldx, L + (int64_t)jb * 64 * ldl, ldl, jb * 64, acc, smem);
+      gemm_tile_g<T, 64, 64>(Xs + k0, ldx, L + (int64_t)jb * 64 * ldl + k0, ldl, jb * 64 - k0, acc, smem);
       store_tile<T, 64, 64, 0>(Xj, ldx, acc);
       __syncthreads();
     }
@@ -469,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void trsm_rlt_kernel(T* X, int64_t ldx, con
     // gemm_tile ends with a barrier: every read of T is complete
     store_tile<T, 64, 64, 1>(Xj, ldx, acc);
     if (Ps) store_tile<T, 64, 64, 1>(Ps + jb * 64, ldp, acc);
+    if (Wt) store_tile_transposed<T>(Wt + (int64_t)jb * 64 * ldw + (int64_t)blockIdx.x * 64, ldw, acc, (T)1);
     __syncthreads();
   }
 }
@@ -520,7 +579,7 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
   } else {  // rectangle; lower == 2: masked to tj <= ti; lower == 3: block-cyclic mask
     int sh;
     dim3 grid((unsigned)rect_grid(tm, tn, sh));
-    const int mask = lower == 2 ? 1 : lower == 3 ? 2 : 0;
+    const int mask = lower == 2 ? 1 : lower == 3 ? 2 : lower == 4 ? 4 : 0;
     if (mode == 0)
       hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
     else
@@ -546,7 +605,18 @@ void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
     return;
   }
   hipLaunchKernelGGL(trsm_rlt_kernel<T>, dim3((unsigned)(rows / 64)), dim3(256), 0, st, X, ldx, L, ldl,
-                     Winv, nb / 64, P, ldp);
+                     Winv, 0, nb / 64, P, ldp, 0, (T*)nullptr, (int64_t)0);
+}
+
+template <typename T>
+void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv, int q0, int q1, T* W,
+                       int64_t ldw, hipStream_t st) {
+  if (((uintptr_t)U | (uintptr_t)(ldu * (int64_t)sizeof(T))) % 128 != 0) {
+    fprintf(stderr, "libgpx: launch_inv_extend: U rows not 128-byte aligned\n");
+    return;
+  }
+  hipLaunchKernelGGL(trsm_rlt_kernel<T>, dim3((unsigned)q1), dim3(256), 0, st, U, ldu, L, ldl, Winv, q0, q1,
+                     (T*)nullptr, (int64_t)0, 1, W, ldw);
 }
 
 template <typename T>
@@ -632,11 +702,19 @@ int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, i
   return n;
 }
 
+#ifdef GPX_STAMPS
+extern "C" int gpx_debug_read_stamps(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gpx_stamp_buf), (size_t)n * 8) == hipSuccess ? 0 : -2;
+}
+#endif
+
 #define GPX_INSTANTIATE_BLAS(T)                                                                         \
   template void launch_potf2_64<T>(T*, int64_t, T*, int64_t, int*, hipStream_t);                        \
   template void launch_trsm_rlt<T>(T*, int64_t, int64_t, const T*, int64_t, const T*, int, T*, int64_t, \
                                    hipStream_t);                                                        \
   template void launch_trsm_rln<T>(T*, int64_t, int64_t, const T*, int64_t, const T*, int, hipStream_t); \
+  template void launch_inv_extend<T>(T*, int64_t, const T*, int64_t, const T*, int, int, T*, int64_t,   \
+                                     hipStream_t);                                                      \
   template void launch_gemm_nt<T>(int, T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,      \
                                   int64_t, int64_t, int, int, hipStream_t);                             \
   template void launch_gemm_nt_bc<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,        \

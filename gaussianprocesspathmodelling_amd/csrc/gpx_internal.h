@@ -52,6 +52,13 @@ void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipSt
 template <typename T>
 void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, const T* Winv, int nb,
                      T* P, int64_t ldp, hipStream_t st);
+// Building the explicit inverse of a diagonal block L (nbw x nbw, ldl) next to its
+// factorisation: U (ldu) holds (L^-1)^T column blocks [0, q0) already and the identity elsewhere;
+// this solves column blocks [q0, q1) of U for row blocks 0..q1-1 and writes them transposed into
+// row blocks [q0, q1) of W = L^-1 (ldw).  Needs the 64-block inverses and rows of L up to q1.
+template <typename T>
+void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv, int q0, int q1, T* W,
+                       int64_t ldw, hipStream_t st);
 // X (rows x nb, ldx) <- X * L^-1 (right, lower, no-transpose; descending blocks).
 template <typename T>
 void launch_trsm_rln(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, const T* Winv, int nb,
@@ -59,7 +66,8 @@ void launch_trsm_rln(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
 // C (m x n, ldc) op= A (m x k, lda) * B (n x k, ldb)^T.
 //   mode 0: C -= A B^T      mode 1: C = A B^T
 //   lower 0: every tile;  1: lower triangle (m == n), triangular super-tile order;
-//         2: rectangle masked to tile_col <= tile_row (look-ahead strip).
+//         2: rectangle masked to tile_col <= tile_row (look-ahead strip);
+//         4: every tile, B lower triangular (k limited to the tile's own column range).
 //   tile = 128 (m,n multiples of 128) or 64 (multiples of 64); k multiple of 64.
 template <typename T>
 void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
@@ -86,6 +94,9 @@ void launch_unpack_rhs(const T* YT, int64_t ld, int64_t n, int k, double scale, 
 template <typename T>
 void launch_var_rows(const T* VT, int64_t ld, int64_t m, int64_t ncols, double sf2, T* var,
                      hipStream_t st);
+// A[i][i] = 1 for i < n
+template <typename T>
+void launch_set_diag_one_t(T* A, int64_t lda, int64_t n, hipStream_t st);
 // out[0] = 2 * sum_{i<n} log(A[i, i])  (fp64 accumulation and result).
 template <typename T>
 void launch_logdet(const T* A, int64_t lda, int64_t n, double* out, hipStream_t st);

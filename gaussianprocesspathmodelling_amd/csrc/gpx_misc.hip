@@ -57,6 +57,12 @@ __global__ __launch_bounds__(256) void var_rows_kernel(const T* __restrict__ VT,
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void set_diag_one_kernel_t(T* A, int64_t lda, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) A[i * lda + i] = (T)1;
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void logdet_kernel(const T* __restrict__ A, int64_t lda, int64_t n,
                                                     double* __restrict__ out) {
   __shared__ double red[4];
@@ -284,6 +290,11 @@ void launch_var_rows(const T* VT, int64_t ld, int64_t m, int64_t ncols, double s
 }
 
 template <typename T>
+void launch_set_diag_one_t(T* A, int64_t lda, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(set_diag_one_kernel_t<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, lda, n);
+}
+
+template <typename T>
 void launch_logdet(const T* A, int64_t lda, int64_t n, double* out, hipStream_t st) {
   hipLaunchKernelGGL(logdet_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, n, out);
 }
@@ -292,7 +303,8 @@ void launch_logdet(const T* A, int64_t lda, int64_t n, double* out, hipStream_t 
   template void launch_pack_rhs<T>(const T*, int64_t, int, T*, int64_t, int64_t, int, hipStream_t); \
   template void launch_unpack_rhs<T>(const T*, int64_t, int64_t, int, double, T*, hipStream_t);     \
   template void launch_var_rows<T>(const T*, int64_t, int64_t, int64_t, double, T*, hipStream_t);   \
-  template void launch_logdet<T>(const T*, int64_t, int64_t, double*, hipStream_t);
+  template void launch_logdet<T>(const T*, int64_t, int64_t, double*, hipStream_t);                 \
+  template void launch_set_diag_one_t<T>(T*, int64_t, int64_t, hipStream_t);
 GPX_INSTANTIATE_MISC(double)
 GPX_INSTANTIATE_MISC(float)
 
