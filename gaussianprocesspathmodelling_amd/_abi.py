@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libgpx.so")
 ABI_VERSION = 2
 
 KERNEL_IDS = {"rbf": 0, "matern52": 1}
-DTYPE_IDS = {"float64": 0, "float32": 1}
+DTYPE_IDS = {"float64": 0, "float32": 1, "mixed": 2}
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_PROFILE = 1
 TRANSPORT_IDS = {None: 0, "auto": 0, "rccl": 1, "local": 2}
@@ -24,7 +24,7 @@ class GpxConfig(C.Structure):
     _fields_ = [("kernel", C.c_int32), ("dtype", C.c_int32), ("device", C.c_int32),
                 ("block", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
                 ("flags", C.c_int32), ("ndev", C.c_int32), ("devices", C.c_int32 * MAX_GROUP),
-                ("transport", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("transport", C.c_int32), ("refine", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class GpxTimings(C.Structure):
@@ -33,7 +33,8 @@ class GpxTimings(C.Structure):
                  "kstar", "mean", "trsm", "var", "d2h", "predict_total",
                  "comm", "chol_diag", "chol_trsm", "chol_strip", "chol_syrk", "syrk_flops")] + \
                [("syrk_launches", C.c_int64), ("kbuild_bytes", C.c_double)] + \
-               [(n, C.c_double) for n in ("grad_trtri", "grad_trace", "grad_total")]
+               [(n, C.c_double) for n in ("grad_trtri", "grad_trace", "grad_total", "refine", "refine_resid0",
+                                          "refine_resid")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

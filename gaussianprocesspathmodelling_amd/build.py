@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["gpx_api.hip", "gpx_blas.hip", "gpx_grad.hip", "gpx_kbuild.hip", "gpx_misc.hip", "gpx_paths.hip"]
+SOURCES = ["gpx_api.hip", "gpx_blas.hip", "gpx_grad.hip", "gpx_kbuild.hip", "gpx_misc.hip", "gpx_mixed.hip", "gpx_paths.hip"]
 HEADERS = ["gpx_internal.h", "gpx_tile.h", "gpx_shard.inc", "gpx_group.inc", os.path.join("..", "..", "include", "gpx.h")]
 LIB = os.path.join(CSRC, "libgpx.so")
 ARCH = "gfx950"

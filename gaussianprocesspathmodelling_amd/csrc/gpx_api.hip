@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -88,6 +89,9 @@ struct gpx_handle {
   bool alpha_ready = false;
   DevBuf AT;
   DevBuf ZT, gpart;  // gpx_lml_grad: L^-T (Npad x ld) and the per-tile partial sums
+  // GPX_MIXED: fp64 side of the mixed-precision mode (the fp32 engine uses the buffers above)
+  DevBuf X64, Y64, Xs64, A64, R64, X32, Y32, RT32, Q64, Qs64, Q32, M64, rn;
+  int refine = 3;
   DevBuf Tsol;       // predict: compact solved blocks of V^T (2 x batch x (nb + skew))
   DevBuf Wblk, Ublk; // explicit inverses of the nb x nb diagonal blocks of L ([Npad/nb][nb][nb]) + scratch
   int nbw = 0;       // block width of Wblk (0: not built)
@@ -790,6 +794,137 @@ int lml_grad_impl(gpx_handle* h, double* lml, double* grad) {
   return GPX_OK;
 }
 
+// ---- GPX_MIXED: fp32 factorisation, fp64 refinement of alpha, fp64 mean --------------------------
+constexpr int MIXED_KMAX = 8;
+
+void launch_rows_sumsq_y(gpx_handle* h, double* out) {  // ||y||^2: y (N x k) is one row of N k values
+  launch_rows_sumsq((const double*)h->Y64.p, 0, 1, h->N * h->k, out, h->st);
+}
+
+int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
+              const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter, int32_t mem_kind,
+              int64_t* info) {
+  if (k > MIXED_KMAX) return fail(h, GPX_E_ARG, "gpx_fit: the mixed-precision mode takes at most 8 target columns");
+  const int64_t Npad = round_up(N, TILE);
+  int rc;
+  if ((rc = ensure(h, h->X64, (size_t)N * d * 8))) return rc;
+  if ((rc = ensure(h, h->Y64, (size_t)N * k * 8))) return rc;
+  if ((rc = ensure(h, h->Xs64, (size_t)Npad * d * 8))) return rc;
+  if ((rc = ensure(h, h->X32, (size_t)N * d * 4))) return rc;
+  if ((rc = ensure(h, h->Y32, (size_t)N * k * 4))) return rc;
+  if ((rc = ensure(h, h->A64, (size_t)MIXED_KMAX * Npad * 8))) return rc;
+  if ((rc = ensure(h, h->R64, (size_t)MIXED_KMAX * Npad * 8))) return rc;
+  if ((rc = ensure(h, h->rn, 64))) return rc;
+  if ((rc = ensure(h, h->ls, 32 * 8))) return rc;
+  hipStream_t st = h->st;
+  if ((rc = copy_in(h, h->X64.p, X, (size_t)N * d * 8, mem_kind))) return rc;
+  if ((rc = copy_in(h, h->Y64.p, y, (size_t)N * k * 8, mem_kind))) return rc;
+  launch_f64_to_f32((const double*)h->X64.p, (float*)h->X32.p, N * d, st);
+  launch_f64_to_f32((const double*)h->Y64.p, (float*)h->Y32.p, N * k, st);
+  // the whole fp32 fit (kernel build, blocked Cholesky, z = L^-1 y) on the device copies
+  if ((rc = fit_impl<float>(h, h->X32.p, h->Y32.p, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, GPX_MEM_DEVICE,
+                            info)))
+    return rc;
+  gpx_timings& tm = h->tm;
+  tm.refine = tm.refine_resid0 = tm.refine_resid = 0;
+  if (*info != 0) return GPX_OK;
+  const int64_t ld32 = h->ld;
+  if ((rc = ensure(h, h->RT32, (size_t)RHS_ROWS * ld32 * 4))) return rc;
+  if ((rc = ensure_alpha<float>(h))) return rc;
+  double* A64 = (double*)h->A64.p;
+  double* R64 = (double*)h->R64.p;
+  double* rn = (double*)h->rn.p;
+  const double* Xs64 = (const double*)h->Xs64.p;
+  const float* L32 = (const float*)h->Lfac;
+  double hn[3] = {0, 0, 0};
+  {
+    PhaseScope ps(h, &tm.refine);
+    launch_scale_points<double>((const double*)h->X64.p, N, Npad, d, (const double*)h->ls.p, n_ls, (double*)h->Xs64.p,
+                                st);
+    HIPCHK(h, hipMemsetAsync(A64, 0, (size_t)MIXED_KMAX * Npad * 8, st));
+    launch_rows_add_f32_to_f64((const float*)h->alphaT, ld32, A64, Npad, k, N, Npad, 0, st);
+    launch_rows_sumsq_y(h, rn + 2);  // ||y||^2
+    for (int it = 0; it <= h->refine; ++it) {
+      // r = y - (K + diag I) alpha  (fp64, matrix-free)
+      launch_kmatvec(h->cfg.kernel, Xs64, N, Npad, Xs64, Npad, d, sf2, sn2 + jitter, (const double*)h->Y64.p, A64,
+                     Npad, k, -1.0, R64, Npad, st);
+      if (it == 0) launch_rows_sumsq(R64, Npad, k, N, rn, st);
+      if (it == h->refine) {
+        launch_rows_sumsq(R64, Npad, k, N, rn + 1, st);
+        break;
+      }
+      // delta = (L L^T)^-1 r in fp32; alpha += delta in fp64
+      launch_rows_f64_to_f32(R64, Npad, (float*)h->RT32.p, ld32, k, RHS_ROWS, N, Npad, st);
+      if ((rc = solve_fwd_enqueue<float>(h, (float*)h->RT32.p, RHS_ROWS, L32, ld32, Npad, h->nb_solve,
+                                         (const float*)h->Winv.p)))
+        return rc;
+      solve_bwd_enqueue<float>(h, (float*)h->RT32.p, RHS_ROWS, L32, ld32, Npad, h->nb_solve, (const float*)h->Winv.p);
+      launch_rows_add_f32_to_f64((const float*)h->RT32.p, ld32, A64, Npad, k, N, Npad, 1, st);
+    }
+  }
+  HIPCHK(h, hipMemcpyAsync(hn, rn, 24, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, hipGetLastError());
+  collect_phases(h);
+  tm.fit_total += tm.refine;
+  if (hn[2] > 0) {
+    tm.refine_resid0 = std::sqrt(hn[0] / hn[2]);
+    tm.refine_resid = std::sqrt(hn[1] / hn[2]);
+  }
+  return GPX_OK;
+}
+
+int mixed_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var, int32_t mem_kind) {
+  const int64_t N = h->N, Npad = h->Npad;
+  const int d = h->d, k = h->k;
+  const int64_t Mpad = round_up(M, TILE);
+  gpx_timings& tm = h->tm;
+  tm.kstar = tm.mean = tm.trsm = tm.var = tm.d2h = tm.predict_total = 0;
+  int rc;
+  if ((rc = ensure(h, h->Q64, (size_t)M * d * 8))) return rc;
+  if ((rc = ensure(h, h->Qs64, (size_t)Mpad * d * 8))) return rc;
+  if ((rc = ensure(h, h->Q32, (size_t)M * d * 4))) return rc;
+  if ((rc = ensure(h, h->M64, (size_t)(MIXED_KMAX * Mpad + (size_t)M * k + Mpad) * 8))) return rc;
+  double* MT64 = (double*)h->M64.p;            // [8][Mpad] transposed means
+  double* mout = MT64 + MIXED_KMAX * Mpad;     // (M x k)
+  double* vout = mout + (size_t)M * k;         // (M)
+  hipStream_t st = h->st;
+  {
+    PhaseScope total(h, &tm.predict_total);
+    if ((rc = copy_in(h, h->Q64.p, Xq, (size_t)M * d * 8, mem_kind))) return rc;
+    if (var) {  // variance through the fp32 factor (its own K*, V^T = K* L^-T, row sums)
+      launch_f64_to_f32((const double*)h->Q64.p, (float*)h->Q32.p, M * d, st);
+      if ((rc = predict_core<float>(h, h->Q32.p, M, true, GPX_MEM_DEVICE))) return rc;
+      launch_f32_to_f64((const float*)h->var.p, vout, M, st);
+    }
+    {
+      PhaseScope ps(h, &tm.mean);
+      launch_scale_points<double>((const double*)h->Q64.p, M, Mpad, d, (const double*)h->ls.p, h->n_ls,
+                                  (double*)h->Qs64.p, st);
+      launch_kmatvec(h->cfg.kernel, (const double*)h->Qs64.p, M, Mpad, (const double*)h->Xs64.p, Npad, d, h->sf2,
+                     0.0, nullptr, (const double*)h->A64.p, Npad, k, 1.0, MT64, Mpad, st);
+      launch_unpack_rhs<double>(MT64, Mpad, M, k, 1.0, mout, st);
+    }
+    PhaseScope ps(h, &tm.d2h);
+    if ((rc = copy_out(h, mean, mout, (size_t)M * k * 8, mem_kind))) return rc;
+    if (var && (rc = copy_out(h, var, vout, (size_t)M * 8, mem_kind))) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, hipGetLastError());
+  collect_phases(h);
+  (void)N;
+  return GPX_OK;
+}
+
+int mixed_alpha(gpx_handle* h, void* out) {
+  int rc;
+  if ((rc = ensure(h, h->M64, (size_t)h->N * h->k * 8))) return rc;
+  launch_unpack_rhs<double>((const double*)h->A64.p, h->Npad, h->N, h->k, 1.0, (double*)h->M64.p, h->st);
+  HIPCHK(h, hipMemcpyAsync(out, h->M64.p, (size_t)h->N * h->k * 8, hipMemcpyDeviceToHost, h->st));
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  return GPX_OK;
+}
+
 template <typename T>
 int alpha_impl(gpx_handle* h, void* out) {
   int rc;
@@ -826,10 +961,11 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) try {
   *out = nullptr;
   if (cfg->kernel != GPX_KERNEL_RBF && cfg->kernel != GPX_KERNEL_MATERN52)
     return fail(nullptr, GPX_E_ARG, "gpx_create: unknown kernel id");
-  if (cfg->dtype != GPX_F64 && cfg->dtype != GPX_F32)
+  if (cfg->dtype != GPX_F64 && cfg->dtype != GPX_F32 && cfg->dtype != GPX_MIXED)
     return fail(nullptr, GPX_E_ARG, "gpx_create: unknown dtype id");
-  if (cfg->dtype == GPX_F32 && cfg->world > 1)
+  if (cfg->dtype != GPX_F64 && cfg->world > 1)
     return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: the row-block shard is fp64 only");
+  if (cfg->refine < 0 || cfg->refine > 50) return fail(nullptr, GPX_E_ARG, "gpx_create: need 0 <= refine <= 50");
   if (cfg->world < 1 || cfg->world > 64 || cfg->rank < 0 || cfg->rank >= cfg->world)
     return fail(nullptr, GPX_E_ARG, "gpx_create: need 1 <= world <= 64 and 0 <= rank < world");
   if (cfg->ndev < 0 || cfg->ndev > GPX_MAX_GROUP)
@@ -854,6 +990,7 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) try {
   h->cfg = *cfg;
   h->cfg.device = device;
   h->nb = nb;
+  h->refine = cfg->refine > 0 ? cfg->refine : 3;
   if (const char* e = getenv("GPX_NB_SHARD")) h->nb_shard_env = atoi(e);
   if (h->nb_shard_env < 128 || h->nb_shard_env > 2048 || h->nb_shard_env % 128 != 0) h->nb_shard_env = 0;
   // tuning overrides; anything that is not a multiple of 128 in [128, 2048] is ignored
@@ -896,7 +1033,8 @@ void gpx_destroy(gpx_handle* h) {
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout, &h->G, &h->Pglob,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
-                    &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->gpart, &h->Wblk, &h->Ublk, &h->Tsol})
+                    &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->gpart, &h->Wblk, &h->Ublk, &h->Tsol, &h->X64, &h->Y64, &h->Xs64,
+                    &h->A64, &h->R64, &h->X32, &h->Y32, &h->RT32, &h->Q64, &h->Qs64, &h->Q32, &h->M64, &h->rn})
     release(*b);
   destroy_comm(h);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
@@ -931,6 +1069,8 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
   if (h->cfg.world > 1 || h->comm)  // a 1-rank communicator also takes the sharded schedule
     return shard_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
 
+  if (h->cfg.dtype == GPX_MIXED)
+    return mixed_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
   if (h->cfg.dtype == GPX_F32)
     return fit_impl<float>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
   return fit_impl<double>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
@@ -949,6 +1089,7 @@ int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var,
   h->phases.clear();
   h->ev_used = 0;
   if (h->cfg.world > 1 || h->comm) return shard_predict(h, Xq, M, mean, var, mem_kind);
+  if (h->cfg.dtype == GPX_MIXED) return mixed_predict(h, Xq, M, mean, var, mem_kind);
   if (h->cfg.dtype == GPX_F32) return predict_impl<float>(h, Xq, M, mean, var, mem_kind);
   return predict_impl<double>(h, Xq, M, mean, var, mem_kind);
 }
@@ -964,6 +1105,7 @@ int gpx_get_alpha(gpx_handle* h, void* out) try {
     return rc;
   }
   HIPCHK(h, hipSetDevice(h->cfg.device));
+  if (h->cfg.dtype == GPX_MIXED) return mixed_alpha(h, out);
   if (h->cfg.dtype == GPX_F32) return alpha_impl<float>(h, out);
   return alpha_impl<double>(h, out);
 }

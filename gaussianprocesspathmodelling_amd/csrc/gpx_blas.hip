@@ -230,6 +230,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stair_kernel(
   store_tile<T, BT, BT, MODE>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
 }
 
+// ---- experimental 256x128 tile, 8 waves (4 x 2, each 64x64): one workgroup per CU ------------
+// Lower triangle of C (m == n, multiples of 256) -= A A^T-style NT product.  Tile row ti (256
+// rows) owns tile columns tj <= 2 ti + 1 (128 wide): the staircase map with P = 2, tpb = 1,
+// c = 1; the part of a straddling tile above the diagonal lands in the never-read upper triangle.
+// Same per-wave work as the 128x128 engine at 25 % fewer LDS-DMA bytes per flop, but all eight
+// waves of a CU now share one barrier.  Selected by GPX_SYRK_TALL=1 (A/B measurement only).
+template <typename T, int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_nt_tall_kernel(
+    T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+    int64_t ldb, int tiles_m, int tiles_n, BcMask bc, int K, StairMap map) {
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 256, 128>::SMEM_ELEMS];
+  const unsigned lin = (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_chunk_id(blockIdx.x, gridDim.x));
+  int ti, tj;
+  stair_coords(map, bc, lin, tiles_m, tiles_n, ti, tj);
+  if (ti >= tiles_m || tj >= tiles_n) return;
+  typename Num<T>::v4 acc[4][4];
+  zero_acc(acc);
+  gemm_tile_g<T, 256, 128, 4>(A + (int64_t)ti * 256 * lda, lda, B + (int64_t)tj * 128 * ldb, ldb, K, acc, smem);
+  store_tile<T, 256, 128, MODE, 4>(C + (int64_t)ti * 256 * ldc + (int64_t)tj * 128, ldc, acc);
+}
+
 // ---- C -= A * B, B stored [k][n]; 64x64 tiles --------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(T* __restrict__ C, int64_t ldc,
@@ -630,6 +651,18 @@ template <typename T>
 void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                     int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st) {
   if (m <= 0 || n <= 0) return;
+  static const bool tall = [] {
+    const char* e = getenv("GPX_SYRK_TALL");
+    return e && atoi(e) != 0;
+  }();
+  if (tall && lower == 1 && mode == 0 && tile == 128 && m == n && m % 256 == 0 && m / 256 <= 8 * STAIR_MAX) {
+    const BcMask bc2{2, 1, 1};
+    StairMap map;
+    const unsigned total = build_stair_map(bc2, m / 256, n / 128, map);
+    hipLaunchKernelGGL((gemm_nt_tall_kernel<T, 0>), dim3(total), dim3(512), 0, st, C, ldc, A, lda, B, ldb,
+                       (int)(m / 256), (int)(n / 128), bc2, (int)k, map);
+    return;
+  }
   const BcMask bc{0, 1, 0};
   if (tile == 128)
     launch_gemm_nt_t<T, 128>(C, ldc, A, lda, B, ldb, m, n, k, lower, mode, bc, st);

@@ -126,6 +126,23 @@ void launch_reduce_partials(const double* part, int64_t ntile, int ntheta, doubl
 void launch_dot_rhs(const double* y, const double* alphaT, int64_t ld, int64_t n, int k, double* out,
                     hipStream_t st);
 
+// ---- mixed precision (gpx_mixed.hip) ------------------------------------------------------------
+// outT[c][i] = (y ? y[i*k+c] : 0) + sign * (sum_j sf2 k(a_i, b_j) alphaT[c][j] + diag * alphaT[c][i]), i < m;
+// fp64, matrix-free (K regenerated from the scaled points As (mpad x d) / Bs (npad x d)); k <= 8;
+// alphaT (k x lda) zero beyond the valid columns.
+void launch_kmatvec(int kernel, const double* As, int64_t m, int64_t mpad, const double* Bs, int64_t npad, int d,
+                    double sf2, double diag, const double* y, const double* alphaT, int64_t lda, int k,
+                    double sign, double* outT, int64_t ldo, hipStream_t st);
+void launch_f64_to_f32(const double* in, float* out, int64_t count, hipStream_t st);
+void launch_f32_to_f64(const float* in, double* out, int64_t count, hipStream_t st);
+// dst (R x ldd, float) = rows [0, rows) x [0, n) of src (double), zero elsewhere up to npad
+void launch_rows_f64_to_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int rows, int R, int64_t n,
+                            int64_t npad, hipStream_t st);
+// dst (rows x ldd, double) (+)= src (float) on [0, n), (acc ? unchanged : 0) beyond
+void launch_rows_add_f32_to_f64(const float* src, int64_t lds, double* dst, int64_t ldd, int rows, int64_t n,
+                                int64_t npad, int acc, hipStream_t st);
+void launch_rows_sumsq(const double* src, int64_t lds, int rows, int64_t n, double* out, hipStream_t st);
+
 // ---- path distance (gpx_paths.hip) -----------------------------------------------------------
 // D (P, ldd)[p][c] = sum_i ||paths[p][i] - cents[c][i]||, paths (P, L, 2), cents (C <= 64, L <= 64, 2)
 void launch_path_distance(const double* paths, int64_t P, const double* cents, int C, int L, double* D,

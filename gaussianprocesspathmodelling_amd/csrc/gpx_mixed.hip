@@ -1,0 +1,177 @@
+// gpx_mixed.hip — kernels of the mixed-precision mode (BASELINE.json configs[4]: "fp32 + ARD
+// lengthscales — mixed-precision tolerance study").  The factorisation
+// runs in fp32 on the fp32 MFMA engine (2x the fp64 rate); alpha is then refined in fp64:
+//     r = y - K alpha        fp64, K regenerated from the scaled points on the fly (never stored)
+//     L L^T delta = r        fp32 solves with the fp32 factor
+//     alpha += delta         fp64
+// and the posterior mean is K* alpha in fp64 through the same matrix-free product.  The
+// reference has no counterpart (GPmap.py has no GP code); restated by tests against the fp64
+// oracle (oracle/gp_oracle.py).
+#include "gpx_internal.h"
+
+namespace gpx {
+namespace {
+
+constexpr double SQRT5 = 2.23606797749978969640917366873128;
+constexpr int XMAXD = 32;
+constexpr int KMAX = 8;  // target columns of the mixed mode
+
+template <int KERNEL>
+__device__ __forceinline__ double kval(double r2, double sf2) {
+  if (KERNEL == 0) return sf2 * exp(-0.5 * r2);
+  const double s = SQRT5 * sqrt(r2);
+  return sf2 * ((1.0 + s + s * s / 3.0) * exp(-s));
+}
+
+// outT[c][i] = (y ? y[i*k + c] : 0) + sign * (sum_j sf2 k(a_i, b_j) alphaT[c][j] + diag * alphaT[c][i])
+// for i < m (0 beyond), c < k <= KMAX.  As (mpad x d), Bs (npad x d) scaled points, zero rows beyond
+// m / n; alphaT (k x lda) must be zero beyond n.  One workgroup per 64 rows; wave g takes 16 of
+// every 64 columns (lane = row: the column operands are LDS broadcasts); fixed reduction order.
+template <int KERNEL, int D>
+__global__ __launch_bounds__(256) void kmatvec_kernel(const double* __restrict__ As, int64_t m,
+                                                     const double* __restrict__ Bs, int64_t npad, int d_rt,
+                                                     double sf2, double diag, const double* __restrict__ y,
+                                                     const double* __restrict__ alphaT, int64_t lda, int k,
+                                                     double sign, double* __restrict__ outT, int64_t ldo) {
+  __shared__ double xb[64 * XMAXD];
+  __shared__ double ab[KMAX * 64];
+  __shared__ double red[3 * 64 * KMAX];
+  const int d = (D > 0) ? D : d_rt;
+  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  double xa[D > 0 ? D : XMAXD];
+  for (int c = 0; c < d; ++c) xa[c] = As[i * d + c];  // padded rows are readable
+  double acc[KMAX];
+#pragma unroll
+  for (int c = 0; c < KMAX; ++c) acc[c] = 0.0;
+  for (int64_t j0 = 0; j0 < npad; j0 += 64) {
+    for (int e = tid; e < 64 * d; e += 256) xb[e] = Bs[j0 * d + e];
+    for (int e = tid; e < k * 64; e += 256) ab[e] = alphaT[(int64_t)(e >> 6) * lda + j0 + (e & 63)];
+    __syncthreads();
+#pragma unroll 4
+    for (int jj = g * 16; jj < g * 16 + 16; ++jj) {
+      double r2 = 0.0;
+      if (D > 0) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          const double e = xa[c] - xb[jj * D + c];
+          r2 += e * e;
+        }
+      } else {
+        for (int c = 0; c < d; ++c) {
+          const double e = xa[c] - xb[jj * d + c];
+          r2 += e * e;
+        }
+      }
+      const double kf = kval<KERNEL>(r2, sf2);
+#pragma unroll
+      for (int c = 0; c < KMAX; ++c)
+        if (c < k) acc[c] += kf * ab[c * 64 + jj];
+    }
+    __syncthreads();
+  }
+  if (g > 0) {
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) red[((g - 1) * 64 + lane) * KMAX + c] = acc[c];
+  }
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c)
+      if (c < k) {
+        double v = acc[c];
+        for (int q = 0; q < 3; ++q) v += red[(q * 64 + lane) * KMAX + c];
+        double out = 0.0;
+        if (i < m) out = (y ? y[i * k + c] : 0.0) + sign * (v + diag * alphaT[(int64_t)c * lda + i]);
+        outT[(int64_t)c * ldo + i] = out;
+      }
+  }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void convert_kernel(const TI* __restrict__ in, TO* __restrict__ out,
+                                                     int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    out[i] = (TO)in[i];
+}
+
+// dst (R x ldd, TO) [r][i] = r < rows && i < n ? scale * src[r][i] + (acc ? dst : 0) : (acc ? dst : 0)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void rows_axpy_kernel(const TI* __restrict__ src, int64_t lds, TO* __restrict__ dst,
+                                                       int64_t ldd, int rows, int64_t n, int64_t npad, int acc) {
+  const int r = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npad; i += (int64_t)gridDim.x * 256) {
+    const TO v = (r < rows && i < n) ? (TO)src[(int64_t)r * lds + i] : (TO)0;
+    TO* p = dst + (int64_t)r * ldd + i;
+    *p = acc ? *p + v : v;
+  }
+}
+
+// out[0] = sum over rows r < rows, i < n of src[r][i]^2 (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restrict__ src, int64_t lds, int rows,
+                                                        int64_t n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r)
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+      const double v = src[(int64_t)r * lds + i];
+      s += v * v;
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int KERNEL>
+void launch_kmatvec_k(const double* As, int64_t m, int64_t mpad, const double* Bs, int64_t npad, int d, double sf2,
+                      double diag, const double* y, const double* alphaT, int64_t lda, int k, double sign,
+                      double* outT, int64_t ldo, hipStream_t st) {
+  dim3 grid((unsigned)(mpad / 64)), block(256);
+  if (d == 3)
+    hipLaunchKernelGGL((kmatvec_kernel<KERNEL, 3>), grid, block, 0, st, As, m, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo);
+  else
+    hipLaunchKernelGGL((kmatvec_kernel<KERNEL, 0>), grid, block, 0, st, As, m, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo);
+}
+
+}  // namespace
+
+void launch_kmatvec(int kernel, const double* As, int64_t m, int64_t mpad, const double* Bs, int64_t npad, int d,
+                    double sf2, double diag, const double* y, const double* alphaT, int64_t lda, int k,
+                    double sign, double* outT, int64_t ldo, hipStream_t st) {
+  if (kernel == 0)
+    launch_kmatvec_k<0>(As, m, mpad, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo, st);
+  else
+    launch_kmatvec_k<1>(As, m, mpad, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo, st);
+}
+
+void launch_f64_to_f32(const double* in, float* out, int64_t count, hipStream_t st) {
+  if (count <= 0) return;
+  const int64_t bx = (count + 255) / 256;
+  hipLaunchKernelGGL((convert_kernel<double, float>), dim3((unsigned)(bx > 4096 ? 4096 : bx)), dim3(256), 0, st, in, out, count);
+}
+
+void launch_f32_to_f64(const float* in, double* out, int64_t count, hipStream_t st) {
+  if (count <= 0) return;
+  const int64_t bx = (count + 255) / 256;
+  hipLaunchKernelGGL((convert_kernel<float, double>), dim3((unsigned)(bx > 4096 ? 4096 : bx)), dim3(256), 0, st, in, out, count);
+}
+
+void launch_rows_f64_to_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int rows, int R, int64_t n,
+                            int64_t npad, hipStream_t st) {
+  const int64_t bx = (npad + 255) / 256;
+  hipLaunchKernelGGL((rows_axpy_kernel<double, float>), dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, src, lds, dst, ldd, rows, n, npad, 0);
+}
+
+void launch_rows_add_f32_to_f64(const float* src, int64_t lds, double* dst, int64_t ldd, int rows, int64_t n,
+                                int64_t npad, int acc, hipStream_t st) {
+  const int64_t bx = (npad + 255) / 256;
+  hipLaunchKernelGGL((rows_axpy_kernel<float, double>), dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)rows), dim3(256), 0, st, src, lds, dst, ldd, rows, n, npad, acc);
+}
+
+void launch_rows_sumsq(const double* src, int64_t lds, int rows, int64_t n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(rows_sumsq_kernel, dim3(1), dim3(256), 0, st, src, lds, rows, n, out);
+}
+
+}  // namespace gpx

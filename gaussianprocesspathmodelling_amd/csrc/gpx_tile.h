@@ -70,14 +70,15 @@ struct TileShapeG {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),  \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-template <typename T, int BM, int BN>
+// WVM = waves along M (2: 256-thread workgroup, 2 x 2 waves; 4: 512 threads, 4 x 2 waves).
+template <typename T, int BM, int BN, int WVM = 2>
 __device__ __forceinline__ void gemm_tile_g(const T* A, int64_t lda, const T* B, int64_t ldb, int K,
-                                            typename Num<T>::v4 (&acc)[BM / 32][BN / 32], T* smem) {
+                                            typename Num<T>::v4 (&acc)[BM / (16 * WVM)][BN / 32], T* smem) {
   using S = TileShapeG<T, BM, BN>;
   using slot_t = typename Num<T>::slot;
   constexpr int BK = S::BK, SL = Num<T>::SLOT;
-  constexpr int MT = BM / 32, NT = BN / 32, WM = BM / 2, WN = BN / 2;
-  constexpr int IA = BM / 32, IB = BN / 32;  // DMA instructions per wave per k-step
+  constexpr int MT = BM / (16 * WVM), NT = BN / 32, WM = BM / WVM, WN = BN / 2;
+  constexpr int IA = BM / (16 * WVM), IB = BN / (16 * WVM);  // DMA instructions per wave per k-step
   constexpr int RQ = 8 * BK;                 // elements per DMA instruction (8 rows)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -196,17 +197,17 @@ __device__ __forceinline__ void zero_acc(V4 (&acc)[MT][NT]) {
 // (SYRK +0.7 %; the load/store epilogue it replaces cost 2.9 % in the ablation).  C is
 // always the library's own hipMalloc'ed (coarse-grained) memory, where the hardware
 // floating-point atomics are valid.
-template <typename T, int BM, int BN, int MODE>
+template <typename T, int BM, int BN, int MODE, int WVM = 2>
 __device__ __forceinline__ void store_tile(T* C, int64_t ldc,
-                                           const typename Num<T>::v4 (&acc)[BM / 32][BN / 32]) {
+                                           const typename Num<T>::v4 (&acc)[BM / (16 * WVM)][BN / 32]) {
   constexpr int NT = BN / 32;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int l4 = lane >> 4;
-  T* Cw = C + (int64_t)(wr * (BM / 2)) * ldc + wc * (BN / 2) + (lane & 15);
+  T* Cw = C + (int64_t)(wr * (BM / WVM)) * ldc + wc * (BN / 2) + (lane & 15);
 #pragma unroll
-  for (int m = 0; m < BM / 32; ++m) {
+  for (int m = 0; m < BM / (16 * WVM); ++m) {
     T* Cm = Cw + (int64_t)(m * 16) * ldc;
 #pragma unroll
     for (int n = 0; n < NT; ++n)

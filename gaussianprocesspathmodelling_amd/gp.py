@@ -35,7 +35,10 @@ class GP:
     noise : observation-noise variance sn2 (added to the diagonal)
     jitter : extra diagonal term; default 1e-10 * variance
     dtype : "float64" | "float32" (everything, including the factorisation, in fp32:
-        the mixed-precision study of BASELINE.json configs[4]; not a 1e-6 path)
+        the precision study of BASELINE.json configs[4]; not a 1e-6 path) | "mixed" (float64 in and
+        out; the factorisation and the variance in fp32 at twice the MFMA rate, alpha refined in
+        fp64 against the matrix-free fp64 kernel, posterior mean in fp64; at most 8 targets)
+    refine : "mixed" only — refinement iterations (default 3)
     device : HIP device ordinal (default: LOCAL_RANK or 0)
     devices : several GPUs from ONE ordinary Python process: an int n (devices
         0..n-1) or a list of HIP ordinals.  The Gram matrix is sharded in block-cyclic row blocks
@@ -62,7 +65,7 @@ class GP:
     def __init__(self, kernel="rbf", lengthscale=1.0, variance=1.0, noise=1e-2, jitter=None,
                  dtype="float64", device=None, block=0, max_tries=3, profile=False,
                  world=1, rank=0, comm=None, group=None, devices=None, transport=None,
-                 oversubscribe=False):
+                 oversubscribe=False, refine=0):
         if kernel not in _abi.KERNEL_IDS:
             raise ValueError(f"unknown kernel {kernel!r}; expected one of {sorted(_abi.KERNEL_IDS)}")
         if dtype not in _abi.DTYPE_IDS:
@@ -77,7 +80,7 @@ class GP:
             raise ValueError("need variance > 0 and noise >= 0")
         self.jitter = 1e-10 * self.variance if jitter is None else float(jitter)
         self.dtype = dtype
-        self._np_dtype = np.float64 if dtype == "float64" else np.float32
+        self._np_dtype = np.float32 if dtype == "float32" else np.float64
         self.block = int(block)
         self.max_tries = int(max_tries)
         if device is None:
@@ -98,7 +101,7 @@ class GP:
                              device=self.device, block=self.block, rank=self.rank, world=self.world,
                              flags=_abi.FLAG_PROFILE if profile else 0, ndev=len(self.devices),
                              devices=(C.c_int32 * _abi.MAX_GROUP)(*self.devices),
-                             transport=_abi.TRANSPORT_IDS[transport])
+                             transport=_abi.TRANSPORT_IDS[transport], refine=int(refine))
         h = C.c_void_p()
         rc = self._lib.gpx_create(C.byref(h), C.byref(cfg))
         if rc != 0:
@@ -179,7 +182,7 @@ class GP:
         if _is_torch(a):
             import torch
             t = a.detach()
-            tdt = torch.float64 if self.dtype == "float64" else torch.float32
+            tdt = torch.float32 if self.dtype == "float32" else torch.float64
             if t.dtype != tdt:
                 t = t.to(tdt)
             t = t.contiguous()
@@ -242,7 +245,7 @@ class GP:
         mshape = (M,) if self._y1d else (M, self._k)
         if devq is not None:
             import torch
-            tdt = torch.float64 if self.dtype == "float64" else torch.float32
+            tdt = torch.float32 if self.dtype == "float32" else torch.float64
             mean = torch.empty(mshape, dtype=tdt, device=devq)
             var = torch.empty((M,), dtype=tdt, device=devq) if return_var else None
             pm = C.c_void_p(mean.data_ptr())

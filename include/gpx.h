@@ -36,6 +36,8 @@ extern "C" {
 
 #define GPX_F64 0
 #define GPX_F32 1
+#define GPX_MIXED 2 /* inputs / outputs double; factorisation and variance in fp32, alpha refined in \
+                       fp64 against the matrix-free fp64 kernel, posterior mean in fp64 (configs[4]) */
 
 #define GPX_MEM_HOST 0   /* pointers are host memory; library copies H2D/D2H   */
 #define GPX_MEM_DEVICE 1 /* pointers are device memory on the handle's device  */
@@ -76,7 +78,8 @@ typedef struct gpx_config {
   int32_t ndev;                     /* 0 or 1: one device (`device`);  2..GPX_MAX_GROUP: group */
   int32_t devices[GPX_MAX_GROUP];   /* HIP ordinals of the group's ranks                       */
   int32_t transport;                /* GPX_TRANSPORT_*                                         */
-  int32_t reserved[3];
+  int32_t refine;                   /* GPX_MIXED: refinement iterations (0 = default 3)        */
+  int32_t reserved[2];
 } gpx_config;
 
 /* per-phase wall times (ms, hipEvent on the handle's stream) of the LAST
@@ -91,6 +94,8 @@ typedef struct gpx_timings {
   int64_t syrk_launches;
   double kbuild_bytes;                     /* algorithmic bytes of the kernel build */
   double grad_trtri, grad_trace, grad_total; /* gpx_lml_grad: L^-T build, fused K^-1 trace pass, whole call */
+  double refine;                           /* GPX_MIXED: ms spent refining alpha in fp64 */
+  double refine_resid0, refine_resid;      /* ||y - K alpha|| / ||y|| before / after the refinement */
 } gpx_timings;
 
 /* ---- lifecycle ------------------------------------------------------------- */
@@ -102,9 +107,10 @@ const char* gpx_last_error(gpx_handle* h); /* h may be NULL: last error of gpx_c
 
 /* ---- hot path (SURVEY.md §8 rows a1,a3,a4 = fit; a2,a5,a6 = predict) --------- */
 /* K = sf2 k(X,X) + (sn2+jitter) I;  L = chol(K);  alpha = L^-T L^-1 y.
- * X (N,d), y (N,k) row-major, in the dtype of the handle (GPX_F64: double, GPX_F32: float —
- * everything including the factorisation then runs in fp32: config 5, the precision
- * study; unsharded handles only).  lengthscale: n_ls = 1 or d. */
+ * X (N,d), y (N,k) row-major, in the dtype of the handle (GPX_F64 and GPX_MIXED: double,
+ * GPX_F32: float — everything including the factorisation then runs in fp32: config 5, the
+ * precision study; GPX_MIXED: fp32 factorisation + fp64 refinement, k <= 8; both unsharded
+ * handles only).  lengthscale: n_ls = 1 or d. */
 int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
             const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter,
             int32_t mem_kind, int64_t* info);
