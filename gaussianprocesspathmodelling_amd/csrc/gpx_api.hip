@@ -1420,6 +1420,9 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs) try {
   double *sink = nullptr, *src = nullptr, *dst = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const int64_t count = (int64_t)1 << 28;  // 2 GiB per buffer
+  // the two streams must not sit a power of two apart (same HBM channel / bank phase for the read
+  // and the write of every lane): skew the destination by an odd number of 256-byte pieces
+  const int64_t skew = 8 * 1024 + 32 * 37;
   int iters = 65536;  // ~0.23 s: long enough to be past the clock ramp (a 14 ms loop read 75 TF,
                       // the sustained rate is 77.8); GPX_MICROBENCH_ITERS overrides
   if (const char* e = getenv("GPX_MICROBENCH_ITERS")) {
@@ -1431,7 +1434,7 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs) try {
   int rc = GPX_OK;
   TCHK(hipMalloc(&sink, 64));
   TCHK(hipMalloc(&src, (size_t)count * 8));
-  TCHK(hipMalloc(&dst, (size_t)count * 8));
+  TCHK(hipMalloc(&dst, (size_t)(count + skew) * 8));
   TCHK(hipEventCreate(&e0));
   TCHK(hipEventCreate(&e1));
   TCHK(hipMemsetAsync(src, 0x11, (size_t)count * 8, st));
@@ -1442,9 +1445,9 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs) try {
   TCHK(hipEventSynchronize(e1));
   TCHK(hipEventElapsedTime(&ms, e0, e1));
   *mfma_tflops = (double)blocks * 4 * (double)iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
-  launch_copy(src, dst, count, st);  // warm-up
+  launch_copy(src, dst + skew, count, st);  // warm-up
   TCHK(hipEventRecord(e0, st));
-  for (int r = 0; r < 5; ++r) launch_copy(src, dst, count, st);
+  for (int r = 0; r < 5; ++r) launch_copy(src, dst + skew, count, st);
   TCHK(hipEventRecord(e1, st));
   TCHK(hipEventSynchronize(e1));
   TCHK(hipEventElapsedTime(&ms, e0, e1));

@@ -585,26 +585,48 @@ int64_t rect_grid(int64_t tm, int64_t tn, int& sh) {
 }
 
 
+// Small grids: when a launch has no more tiles than the chip has CUs, the dispatcher still packs
+// two workgroups onto one CU (64 KB of LDS each) and leaves half the CUs idle — each tile then
+// walks its K at the half-CU rate.  Asking for enough extra (unused) dynamic LDS that only one
+// workgroup fits per CU spreads them out: a lone workgroup runs 1.75x as fast as one of a
+// co-resident pair.  Matters for the panel / block solves and the strips of small
+// problems (BASELINE.json configs[1]); large launches are unaffected.
+inline int cu_count() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  return n;
+}
+
 template <typename T, int BT>
 void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
                       int64_t n, int64_t k, int lower, int mode, BcMask bc, hipStream_t st) {
   const int64_t tm = m / BT, tn = n / BT;
   dim3 block(256);
+  const int64_t live = lower == 1 ? tm * (tm + 1) / 2
+                       : lower == 2 ? tm * tn - std::min(tm, tn) * (std::min(tm, tn) - 1) / 2 - (tn > tm ? (tn - tm) * tm : 0)
+                                    : tm * tn;
+  // 160 KB per CU: static staging (64 KB at BT = 128) + this > 80 KB  =>  one workgroup per CU
+  const unsigned spread = (BT == 128 && live <= cu_count()) ? 32 * 1024 : 0;
   if (lower == 1) {  // full lower triangle, triangular super-tile enumeration
     const int64_t ts = (tm + 7) / 8;
     dim3 grid((unsigned)(ts * (ts - 1) / 2 * 64 + ts * 36));  // tile_coords<TRI>: no masked slots
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 0>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 1>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
   } else {  // rectangle; lower == 2: masked to tj <= ti; lower == 3: block-cyclic mask
     int sh;
     dim3 grid((unsigned)rect_grid(tm, tn, sh));
     const int mask = lower == 2 ? 1 : lower == 3 ? 2 : lower == 4 ? 4 : 0;
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 0>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 0>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 1>), grid, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 1>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
   }
 }
 

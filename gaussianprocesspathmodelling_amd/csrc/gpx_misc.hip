@@ -117,12 +117,16 @@ __global__ __launch_bounds__(256) void copy_kernel(const double2* __restrict__ s
                                                   double2* __restrict__ dst, int64_t count2) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < count2; i += 4 * stride) {
-    const double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a;
-    dst[i + stride] = b;
-    dst[i + 2 * stride] = c;
-    dst[i + 3 * stride] = d;
+  typedef double v2 __attribute__((ext_vector_type(2)));
+  const v2* s2 = reinterpret_cast<const v2*>(src);
+  v2* d2 = reinterpret_cast<v2*>(dst);
+  for (; i + 3 * stride < count2; i += 4 * stride) {  // streaming: nothing of either buffer is reused
+    const v2 a = __builtin_nontemporal_load(s2 + i), b = __builtin_nontemporal_load(s2 + i + stride),
+             c = __builtin_nontemporal_load(s2 + i + 2 * stride), d = __builtin_nontemporal_load(s2 + i + 3 * stride);
+    __builtin_nontemporal_store(a, d2 + i);
+    __builtin_nontemporal_store(b, d2 + i + stride);
+    __builtin_nontemporal_store(c, d2 + i + 2 * stride);
+    __builtin_nontemporal_store(d, d2 + i + 3 * stride);
   }
   for (; i < count2; i += stride) dst[i] = src[i];
 }
