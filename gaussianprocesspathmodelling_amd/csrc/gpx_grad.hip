@@ -60,14 +60,20 @@ __global__ __launch_bounds__(256, 2) void kinv_trace_kernel(const double* __rest
                                                             int tiles, int64_t npad, int64_t n,
                                                             const double* __restrict__ Xs, int d_rt, int ard,
                                                             double sf2, double sn2, double* __restrict__ part,
-                                                            int ntheta) {
+                                                            int ntheta, int64_t nslots) {
   constexpr int BT = 128;
   __shared__ __attribute__((aligned(16))) double smem[TileShapeG<double, BT, BT>::SMEM_ELEMS];
   __shared__ double red[4];
   const int d = (D > 0) ? D : d_rt;
-  const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
+  // Tile (ti, tj) costs (tiles - ti) k-ranges, so handing each XCD one contiguous eighth of the
+  // tile order (xcd_chunk_id, right for the uniform SYRK) gives the first XCD 29 % of the work
+  // and the kernel ran at 31.6 TF.  Deal whole 64-slot groups (one super-tile: what an XCD runs
+  // concurrently, so the L2 sharing inside a group is kept) round-robin over the XCDs instead:
+  // neighbouring groups cost about the same, and the heavy ones still come first.
+  const int64_t b = blockIdx.x, xl = b >> 3;
+  const int64_t lin = (((xl >> 6) << 3) + (b & 7)) * 64 + (xl & 63);
   int ti, tj;
-  if (!tile_coords<true>(lin, tiles, tiles, 8, 0, BcMask{0, 1, 0}, ti, tj)) return;
+  if (lin >= nslots || !tile_coords<true>(lin, tiles, tiles, 8, 0, BcMask{0, 1, 0}, ti, tj)) return;
   Num<double>::v4 acc[4][4];
   zero_acc(acc);
   // rows ti, tj of ZT are zero left of column ti*BT (tj <= ti): start the contraction there
@@ -289,12 +295,13 @@ void launch_kinv_trace_k(const double* ZT, int64_t ld, int64_t npad, int64_t n, 
                          double sf2, double sn2, double* part, int ntheta, hipStream_t st) {
   const int tiles = (int)(npad / 128);
   const int64_t ts = (tiles + 7) / 8;
-  dim3 grid((unsigned)(ts * (ts - 1) / 2 * 64 + ts * 36)), block(256);
+  const int64_t nslots = ts * (ts - 1) / 2 * 64 + ts * 36;
+  dim3 grid((unsigned)((nslots + 511) / 512 * 512)), block(256);  // whole groups of 8 x 64 slots
   switch (d) {
-    case 1: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 1>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta); break;
-    case 2: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 2>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta); break;
-    case 3: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 3>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta); break;
-    default: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 0>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta); break;
+    case 1: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 1>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots); break;
+    case 2: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 2>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots); break;
+    case 3: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 3>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots); break;
+    default: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 0>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots); break;
   }
 }
 
