@@ -144,7 +144,7 @@ def cpu_baseline(n_sample=24576):
     X, y, Xs = synthetic(n_sample, DIM, M_TEST, 12345)
     with threadpool_limits(limits=threads, user_api="blas"):
         t0 = time.perf_counter()
-        gp = OracleGP(KERNEL, LENGTHSCALE, SF2, SN2, jitter=0.0).fit(X, y)
+        gp = OracleGP(KERNEL, LENGTHSCALE, SF2, SN2, jitter=0.0, chol="blocked").fit(X, y)
         t1 = time.perf_counter()
         gp.predict(Xs)
         t2 = time.perf_counter()
@@ -158,7 +158,8 @@ def cpu_baseline(n_sample=24576):
     return {
         "value": (n_sample + M_TEST) / (t2 - t0), "unit": "points/s", "cores": threads,
         "kind": "port",
-        "sample": (f"oracle/gp_oracle.py (NumPy/SciPy) full fit+predict at N={n_sample} (NOT the workload's "
+        "sample": (f"oracle/gp_oracle.py (NumPy/SciPy; level-3 blocked Cholesky — LAPACK potrf of the bundled "
+                   f"OpenBLAS does not parallelise) full fit+predict at N={n_sample} (NOT the workload's "
                    f"N={N_TRAIN}) d={DIM} M={M_TEST} RBF fp64, same generator, {threads} BLAS threads: fit "
                    f"{t1 - t0:.2f} s (kbuild {tm['kbuild']:.0f} ms, chol {tm['chol']:.0f} ms = {chol_gf:.0f} GF/s, "
                    f"solve {tm['solve']:.0f} ms), predict {t2 - t1:.2f} s; EXTRAPOLATED phase-wise to the "

@@ -94,7 +94,7 @@ class OracleGP:
     """NumPy/SciPy exact GP with the same surface as the product ``GP`` class."""
 
     def __init__(self, kernel="rbf", lengthscale=1.0, variance=1.0, noise=1e-2,
-                 jitter=None, max_tries=1):
+                 jitter=None, max_tries=1, chol="lapack"):
         if kernel not in KERNELS:
             raise ValueError(f"unknown kernel {kernel!r}")
         self.kernel = kernel
@@ -103,6 +103,9 @@ class OracleGP:
         self.noise = float(noise)
         self.jitter = 1e-10 * self.variance if jitter is None else float(jitter)
         self.max_tries = int(max_tries)
+        if chol not in ("lapack", "blocked"):
+            raise ValueError("chol must be 'lapack' (scipy.linalg.cholesky) or 'blocked' (chol_lower_blocked)")
+        self.chol = chol
         self.timings_ = {}
 
     # -- fit -----------------------------------------------------------------
@@ -123,7 +126,10 @@ class OracleGP:
                 self.K_corner_ = K[:keep_K_corner, :keep_K_corner].copy()
             t1 = time.perf_counter()
             try:
-                L = cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+                if self.chol == "blocked":      # level-3 blocked variant: scales with the BLAS threads
+                    L = chol_lower_blocked(K)   # (strictly upper triangle keeps K: never read below)
+                else:
+                    L = cholesky(K, lower=True, overwrite_a=True, check_finite=False)
                 self.info_ = 0
                 break
             except np.linalg.LinAlgError:
@@ -219,6 +225,35 @@ def synthetic_problem(N, d, M, seed=12345):
 # -- small linear-algebra pieces used by the kernel unit tests -------------------
 def chol_lower(K):
     return cholesky(np.array(K, dtype=np.float64), lower=True, check_finite=False)
+
+
+def chol_lower_blocked(K, nb=2048, rb=4096):
+    """In-place lower Cholesky of the C-contiguous SPD matrix K by the same right-looking blocked
+    algorithm the HIP path uses (R&W Alg. 2.1 line 2), expressed with level-3 NumPy/SciPy calls:
+    LAPACK potrf only on nb x nb diagonal blocks, triangular solve for the panel, matrix products
+    for the trailing update (row blocks of rb rows, lower part only).  Why it exists: the bundled
+    OpenBLAS `potrf` does not parallelise below N ~ 10^4 (26-32 GF/s at any thread count at
+    N = 8192, profiles/r02_cpu_baseline_host.json) and crashed on the N = 65536 matrix with a
+    16-thread pool, while `dgemm` scales — so this is both the faster CPU baseline and the
+    full-size parity oracle (tools/full_oracle_c3.py).  Returns K (lower triangle = L; the strictly
+    upper triangle is left as it was)."""
+    n = K.shape[0]
+    assert K.shape == (n, n) and K.flags.c_contiguous and K.dtype == np.float64
+    for o in range(0, n, nb):
+        e = min(o + nb, n)
+        Ld = cholesky(K[o:e, o:e], lower=True, check_finite=False)
+        K[o:e, o:e] = Ld
+        if e == n:
+            break
+        # panel: P = A[e:, o:e] Ld^-T, by row blocks (bounded temporaries)
+        for i in range(e, n, rb):
+            j = min(i + rb, n)
+            K[i:j, o:e] = solve_triangular(Ld, K[i:j, o:e].T, lower=True, check_finite=False).T
+        # trailing update, lower part: A[i:j, e:j] -= P[i:j] P[e:j]^T
+        for i in range(e, n, rb):
+            j = min(i + rb, n)
+            K[i:j, e:j] -= K[i:j, o:e] @ K[e:j, o:e].T
+    return K
 
 
 def trsm_right_lower_trans(A, L):

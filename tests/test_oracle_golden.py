@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle.gp_oracle import (OracleGP, chol_lower, kernel_matrix, synthetic_problem,
+from oracle.gp_oracle import (OracleGP, chol_lower, chol_lower_blocked, kernel_matrix, synthetic_problem,
                               trsm_right_lower_trans)
 
 CASES = ["G1", "G2", "G3"]
@@ -131,3 +131,22 @@ def test_oracle_lml_gradient_matches_central_differences(kernel, ls):
         e[i] = h
         fd = (lml(v0 + e) - lml(v0 - e)) / (2 * h)
         assert abs(fd - grad[i]) <= 1e-6 * max(1.0, np.abs(grad).max()), (i, fd, grad[i])
+
+
+def test_blocked_cholesky_matches_lapack_and_golden(golden_dir):
+    """The level-3 blocked CPU Cholesky (the full-size parity oracle and the stronger CPU baseline)
+    against LAPACK potrf and, through OracleGP(chol="blocked"), against the G3 fixture."""
+    rng = np.random.default_rng(4)
+    for n, nb, rb in ((1, 8, 8), (130, 32, 48), (700, 128, 256), (1000, 2048, 4096)):
+        A = rng.standard_normal((n, max(2, n // 3)))
+        K = A @ A.T + n * np.eye(n)
+        L = np.tril(chol_lower_blocked(K.copy(), nb, rb))
+        assert np.max(np.abs(L - chol_lower(K))) <= 1e-13 * np.abs(L).max()
+    g = load(golden_dir, "G3")
+    gp = OracleGP(str(g["kernel"]), g["lengthscale"], float(g["variance"]), float(g["noise"]), jitter=0.0,
+                  chol="blocked").fit(g["X"], g["y"])
+    mean, var = gp.predict(g["Xs"])
+    np.testing.assert_allclose(mean, g["mean"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(var, g["var"], rtol=1e-8, atol=1e-12)
+    with pytest.raises(np.linalg.LinAlgError):
+        chol_lower_blocked(np.zeros((8, 8)), 4, 4)

@@ -7,19 +7,19 @@ the GPU box's host; no GPU involved):
 Records the host CPU model, os.cpu_count(), the scheduler affinity and the cgroup CPU quota of
 THIS process (the box's share of the host is smaller than the host), every BLAS pool
 (threadpoolctl), and then
-  * a thread sweep of the three O(N^3) building blocks at N = 8192 — SciPy `cholesky` (LAPACK
-    potrf of SciPy's bundled OpenBLAS), NumPy `cholesky` (NumPy's OpenBLAS) and a 4096^3 dgemm —
-    which shows where the Cholesky stops scaling (round 1 measured potrf at 30 GF/s with 64
-    threads: the pool was 4x larger than the CPU quota, so its spinning workers throttled the
-    ones doing work);
-  * the NumPy/SciPy oracle (oracle/gp_oracle.py) at N = 8192, M = 4096 with the thread count
-    that sweep found best (median of 3) and with ONE thread (per-core figure).
+  * a thread sweep of the O(N^3) building blocks at N = 8192 — SciPy `cholesky` (LAPACK potrf of
+    SciPy's bundled OpenBLAS), NumPy `cholesky` (NumPy's OpenBLAS), a 4096^3 dgemm and the oracle's
+    level-3 blocked Cholesky — which shows where the Cholesky stops scaling (round 1 measured
+    potrf at 30 GF/s with 64 threads: it does not parallelise at this size at ANY thread count,
+    while dgemm — and with it the blocked variant — does);
+  * the NumPy/SciPy oracle (oracle/gp_oracle.py, blocked Cholesky) at N = 8192, M = 4096 with the
+    thread count that sweep found best (median of 3) and with ONE thread (per-core figure).
 """
 import json, os, platform, subprocess, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from threadpoolctl import threadpool_info, threadpool_limits
-from oracle.gp_oracle import OracleGP, synthetic_problem
+from oracle.gp_oracle import OracleGP, chol_lower_blocked, synthetic_problem
 
 
 def cpu_budget():
@@ -42,10 +42,13 @@ def cpu_budget():
             "usable_cpus": int(max(1, min(aff, quota if quota else aff)))}
 
 
+CHOL = "blocked"      # the oracle's level-3 blocked Cholesky (LAPACK potrf does not scale here)
+
+
 def run(N, M):
     X, y, Xs = synthetic_problem(N, 3, M, seed=12345)
     t0 = time.perf_counter()
-    gp = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
+    gp = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0, chol=CHOL).fit(X, y)
     t1 = time.perf_counter()
     gp.predict(Xs)
     t2 = time.perf_counter()
@@ -67,9 +70,11 @@ def sweep(budget):
             t0 = time.perf_counter(); sl.cholesky(K, lower=True, check_finite=False); t1 = time.perf_counter()
             np.linalg.cholesky(K); t2 = time.perf_counter()
             B @ B; t3 = time.perf_counter()
+            chol_lower_blocked(K.copy()); t4 = time.perf_counter()
         rows.append({"threads": t, "scipy_potrf_gflops": N ** 3 / 3 / (t1 - t0) / 1e9,
                      "numpy_potrf_gflops": N ** 3 / 3 / (t2 - t1) / 1e9,
-                     "dgemm_4096_gflops": 2 * 4096 ** 3 / (t3 - t2) / 1e9})
+                     "dgemm_4096_gflops": 2 * 4096 ** 3 / (t3 - t2) / 1e9,
+                     "blocked_cholesky_gflops": N ** 3 / 3 / (t4 - t3) / 1e9})
         print(rows[-1], file=sys.stderr, flush=True)
     return rows
 
@@ -86,7 +91,7 @@ def main():
            "env": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")},
            "blas": [{k: p.get(k) for k in ("internal_api", "num_threads", "version", "threading_layer", "filepath")} for p in threadpool_info()]}
     out["thread_sweep_N8192"] = sw = sweep(budget)
-    best = max(sw, key=lambda r: r["scipy_potrf_gflops"])["threads"]
+    best = max(sw, key=lambda r: r["blocked_cholesky_gflops"])["threads"]
     out["best_potrf_threads"] = best
     N, M = 8192, 4096
     with threadpool_limits(limits=best):

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """One-off: FULL CPU oracle at the bench size (BASELINE.json configs[2]: N=65536, d=3, RBF,
 fp64, M=4096) against the HIP path — SURVEY.md §4/§8d "65536 (full oracle once; 34 GB host
-RAM)".  Same arithmetic as oracle/gp_oracle.py (cdist -> exp -> scipy cholesky ->
-solve_triangular), done in place to fit one 34.4 GB matrix.  The BLAS pools are limited to the
+RAM)".  Same arithmetic as oracle/gp_oracle.py (cdist -> exp -> Cholesky -> solve_triangular),
+done in place to fit one 34.4 GB matrix; the Cholesky is the oracle's level-3 blocked variant
+(chol_lower_blocked: LAPACK potrf on 2048-blocks, BLAS-3 for the rest — the monolithic potrf of
+the bundled OpenBLAS crashed on this matrix with a 16-thread pool and does not scale anyway).  The BLAS pools are limited to the
 CPUs this process may use (bench.cpu_budget: affinity and cgroup quota).  Prints progress lines
 and one JSON line: parity of the HIP path at the bench size AND the measured full-size CPU
 baseline that bench.py quotes (oracle_points_per_s).
@@ -22,7 +24,8 @@ def main():
     ap.add_argument("--ntrain", type=int, default=65536)
     ap.add_argument("--mtest", type=int, default=4096)
     a = ap.parse_args()
-    from scipy.linalg import cholesky, solve_triangular
+    from scipy.linalg import solve_triangular
+    from oracle.gp_oracle import chol_lower_blocked
     from scipy.spatial import distance as dst
     from threadpoolctl import threadpool_info, threadpool_limits
     from bench import cpu_budget, synthetic
@@ -53,7 +56,7 @@ def main():
     K[np.diag_indices_from(K)] += sn2
     log("cholesky ...")
     t1 = time.time()
-    L = cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    L = chol_lower_blocked(K)
     t_chol = time.time() - t1
     log(f"cholesky done in {t_chol:.1f} s")
     z = solve_triangular(L, y, lower=True, check_finite=False)
