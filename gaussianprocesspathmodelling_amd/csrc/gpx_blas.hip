@@ -130,18 +130,42 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
   const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
   int ti, tj;
-  if (!tile_coords<TRI>(lin, tiles_m, tiles_n, sh, mask_lower & 3, bc, ti, tj)) return;
+  if (!tile_coords<TRI>(lin, tiles_m, tiles_n, sh, mask_lower, bc, ti, tj)) return;
   typename Num<T>::v4 acc[BT / 32][BT / 32];
   zero_acc(acc);
   T* Ct = C + (int64_t)ti * BT * ldc + (int64_t)tj * BT;
-  // mask_lower bit 2: B is lower triangular (an explicit block inverse): rows of tile column tj
-  // are zero right of column (tj + 1) BT
-  if (mask_lower & 4) K = min(K, (tj + 1) * BT);
   gemm_tile_g<T, BT, BT>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc,
                          smem);
   // (a software-pipelined epilogue — strips of C prefetched / kept in flight — measured
   //  0.5-1 % slower than this plain strip-by-strip one: it pushes the kernel to 256 VGPRs)
   store_tile<T, BT, BT, MODE>(Ct, ldc, acc);
+}
+
+// ---- C = A * W^T with W lower triangular (an explicit block inverse): panel / block solves -----
+// Tile column tj only needs k < (tj + 1) BT.  One workgroup takes tile columns tj AND tn - 1 - tj of
+// its tile row, so every workgroup walks the same total k ((tn + 1) BT): with one tile per
+// workgroup the long columns set the time of every round of slots and the launch ran at 56 % of
+// the engine's rate (39 TF at N = 65536).
+template <typename T, int BT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_ltri_kernel(T* __restrict__ C, int64_t ldc,
+                                                              const T* __restrict__ A, int64_t lda,
+                                                              const T* __restrict__ W, int64_t ldw, int tiles_m,
+                                                              int tiles_n, int sh, int K) {
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
+  const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
+  const int half = (tiles_n + 1) >> 1;
+  int ti, tp;
+  if (!tile_coords<false>(lin, tiles_m, half, sh, 0, BcMask{0, 1, 0}, ti, tp)) return;
+  const T* At = A + (int64_t)ti * BT * lda;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int tj = pass == 0 ? tiles_n - 1 - tp : tp;  // the long column first
+    if (pass == 1 && tj == tiles_n - 1 - tp) break;    // odd tile count: the middle column once
+    typename Num<T>::v4 acc[BT / 32][BT / 32];
+    zero_acc(acc);
+    gemm_tile_g<T, BT, BT>(At, lda, W + (int64_t)tj * BT * ldw, ldw, min(K, (tj + 1) * BT), acc, smem);
+    store_tile<T, BT, BT, 1>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
+  }
 }
 
 // ---- the sharded trailing update: C -= A * B^T under the block-cyclic row map ----------
@@ -230,53 +254,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stair_kernel(
   store_tile<T, BT, BT, MODE>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
 }
 
-// ---- persistent variant of the triangular update ------------------------------------------------
-// One workgroup per hardware slot (2 per CU) instead of one per tile: workgroup b of XCD x = b & 7
-// walks tiles start_x + l, start_x + l + 64, ... of that XCD's contiguous chunk of the same
-// hole-free triangular order (l = b >> 3).  The 64 workgroups of an XCD therefore run the 64
-// tiles of ONE super-tile at a time and — the tiles being equal work — stay in the same k-phase,
-// which is what lets them share the 16 panel row blocks through that XCD's L2; dynamic dispatch
-// (a new workgroup whenever a slot frees) lets them drift apart.  Selected by GPX_SYRK_PERSIST=1.
-template <typename T, int BT, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(
-    T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
-    int64_t ldb, int tiles_m, int tiles_n, int K, int64_t total) {
-  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
-  const int64_t x = blockIdx.x & 7, l = blockIdx.x >> 3, per = gridDim.x >> 3;
-  const int64_t q = total >> 3, r = total & 7;
-  const int64_t start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, len = q + (x < r ? 1 : 0);
-  const BcMask bc{0, 1, 0};
-  for (int64_t i = l; i < len; i += per) {
-    int ti, tj;
-    if (!tile_coords<true>(start + i, tiles_m, tiles_n, 8, 0, bc, ti, tj)) continue;
-    typename Num<T>::v4 acc[BT / 32][BT / 32];
-    zero_acc(acc);
-    gemm_tile_g<T, BT, BT>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc, smem);
-    store_tile<T, BT, BT, MODE>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
-  }
-}
-
 // ---- experimental 256x128 tile, 8 waves (4 x 2, each 64x64): one workgroup per CU ------------
 // Lower triangle of C (m == n, multiples of 256) -= A A^T-style NT product.  Tile row ti (256
 // rows) owns tile columns tj <= 2 ti + 1 (128 wide): the staircase map with P = 2, tpb = 1,
 // c = 1; the part of a straddling tile above the diagonal lands in the never-read upper triangle.
 // Same per-wave work as the 128x128 engine at 25 % fewer LDS-DMA bytes per flop, but all eight
 // waves of a CU now share one barrier.  Selected by GPX_SYRK_TALL=1 (A/B measurement only).
-template <typename T, int MODE, int NST>
+template <typename T, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_nt_tall_kernel(
     T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
     int64_t ldb, int tiles_m, int tiles_n, BcMask bc, int K, StairMap map) {
-  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 256, 128>::SMEM_ELEMS / 2 * NST];
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 256, 128>::SMEM_ELEMS];
   const unsigned lin = (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_chunk_id(blockIdx.x, gridDim.x));
   int ti, tj;
   stair_coords(map, bc, lin, tiles_m, tiles_n, ti, tj);
   if (ti >= tiles_m || tj >= tiles_n) return;
   typename Num<T>::v4 acc[4][4];
   zero_acc(acc);
-  if (NST == 3)
-    gemm_tile_g3<T, 256, 128, 4>(A + (int64_t)ti * 256 * lda, lda, B + (int64_t)tj * 128 * ldb, ldb, K, acc, smem);
-  else
-    gemm_tile_g<T, 256, 128, 4>(A + (int64_t)ti * 256 * lda, lda, B + (int64_t)tj * 128 * ldb, ldb, K, acc, smem);
+  gemm_tile_g<T, 256, 128, 4>(A + (int64_t)ti * 256 * lda, lda, B + (int64_t)tj * 128 * ldb, ldb, K, acc, smem);
   store_tile<T, 256, 128, MODE, 4>(C + (int64_t)ti * 256 * ldc + (int64_t)tj * 128, ldc, acc);
 }
 
@@ -636,32 +631,27 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
                       int64_t n, int64_t k, int lower, int mode, BcMask bc, hipStream_t st) {
   const int64_t tm = m / BT, tn = n / BT;
   dim3 block(256);
-  const int64_t live = lower == 1 ? tm * (tm + 1) / 2
+  const int64_t live = lower == 1   ? tm * (tm + 1) / 2
+                       : lower == 4 ? tm * ((tn + 1) / 2)
                        : lower == 2 ? tm * tn - std::min(tm, tn) * (std::min(tm, tn) - 1) / 2 - (tn > tm ? (tn - tm) * tm : 0)
                                     : tm * tn;
   // 160 KB per CU: static staging (64 KB at BT = 128) + this > 80 KB  =>  one workgroup per CU
   const unsigned spread = (BT == 128 && live <= cu_count()) ? 32 * 1024 : 0;
   if (lower == 1) {  // full lower triangle, triangular super-tile enumeration
     const int64_t ts = (tm + 7) / 8;
-    static const bool persist = [] {
-      const char* e = getenv("GPX_SYRK_PERSIST");
-      return e && atoi(e) != 0;
-    }();
-    const int64_t total = ts * (ts - 1) / 2 * 64 + ts * 36;
-    if (persist && BT == 128 && mode == 0 && total > 2 * (int64_t)cu_count()) {
-      hipLaunchKernelGGL((gemm_nt_persist_kernel<T, BT, 0>), dim3((unsigned)(2 * cu_count())), block, 0, st, C, ldc, A, lda,
-                         B, ldb, (int)tm, (int)tn, (int)k, total);
-      return;
-    }
     dim3 grid((unsigned)(ts * (ts - 1) / 2 * 64 + ts * 36));  // tile_coords<TRI>: no masked slots
     if (mode == 0)
       hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 0>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
     else
       hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 1>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+  } else if (lower == 4) {  // C = A W^T, W lower triangular: paired tile columns (mode 1 only)
+    int sh;
+    dim3 grid((unsigned)rect_grid(tm, (tn + 1) / 2, sh));
+    hipLaunchKernelGGL((gemm_nt_ltri_kernel<T, BT>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, (int)k);
   } else {  // rectangle; lower == 2: masked to tj <= ti; lower == 3: block-cyclic mask
     int sh;
     dim3 grid((unsigned)rect_grid(tm, tn, sh));
-    const int mask = lower == 2 ? 1 : lower == 3 ? 2 : lower == 4 ? 4 : 0;
+    const int mask = lower == 2 ? 1 : lower == 3 ? 2 : 0;
     if (mode == 0)
       hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 0>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
     else
@@ -712,20 +702,16 @@ template <typename T>
 void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                     int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st) {
   if (m <= 0 || n <= 0) return;
-  static const int tall = [] {  // 1: two LDS stages (as the 128x128 engine); 2: three stages, counted vmcnt
+  static const bool tall = [] {
     const char* e = getenv("GPX_SYRK_TALL");
-    return e ? atoi(e) : 0;
+    return e && atoi(e) != 0;
   }();
   if (tall && lower == 1 && mode == 0 && tile == 128 && m == n && m % 256 == 0 && m / 256 <= 8 * STAIR_MAX) {
     const BcMask bc2{2, 1, 1};
     StairMap map;
     const unsigned total = build_stair_map(bc2, m / 256, n / 128, map);
-    if (tall == 2)
-      hipLaunchKernelGGL((gemm_nt_tall_kernel<T, 0, 3>), dim3(total), dim3(512), 0, st, C, ldc, A, lda, B, ldb,
-                         (int)(m / 256), (int)(n / 128), bc2, (int)k, map);
-    else
-      hipLaunchKernelGGL((gemm_nt_tall_kernel<T, 0, 2>), dim3(total), dim3(512), 0, st, C, ldc, A, lda, B, ldb,
-                         (int)(m / 256), (int)(n / 128), bc2, (int)k, map);
+    hipLaunchKernelGGL((gemm_nt_tall_kernel<T, 0>), dim3(total), dim3(512), 0, st, C, ldc, A, lda, B, ldb,
+                       (int)(m / 256), (int)(n / 128), bc2, (int)k, map);
     return;
   }
   const BcMask bc{0, 1, 0};

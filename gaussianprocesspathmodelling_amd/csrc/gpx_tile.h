@@ -181,109 +181,6 @@ __device__ __forceinline__ void gemm_tile_g(const T* A, int64_t lda, const T* B,
   }
 }
 
-// Three-stage variant (experimental, for the 8-wave 256x128 tile: one workgroup per CU, so no
-// co-resident workgroup covers a barrier that also has to drain the LDS-DMA).  The DMA of k-step
-// t+2 is issued during step t; before step t a wave waits only until its OWN loads of stage t have
-// landed (`s_waitcnt vmcnt(IA+IB)`: the loads of stage t+1 stay in flight) and then meets the
-// other waves at a bare `s_barrier`.  Buffer (t+2) % 3 = (t-1) % 3 is free by then: a wave reaches
-// barrier t only after the MFMAs that consumed its stage t-1 fragments were issued.
-template <typename T, int BM, int BN, int WVM>
-__device__ __forceinline__ void gemm_tile_g3(const T* A, int64_t lda, const T* B, int64_t ldb, int K,
-                                             typename Num<T>::v4 (&acc)[BM / (16 * WVM)][BN / 32], T* smem) {
-  using S = TileShapeG<T, BM, BN>;
-  using slot_t = typename Num<T>::slot;
-  constexpr int BK = S::BK, SL = Num<T>::SLOT;
-  constexpr int MT = BM / (16 * WVM), NT = BN / 32, WM = BM / WVM, WN = BN / 2;
-  constexpr int IA = BM / (16 * WVM), IB = BN / (16 * WVM);
-  constexpr int RQ = 8 * BK;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  T* As = smem;
-  T* Bs = smem + 3 * S::A_STAGE;
-  const int drow = lane >> 3, dslot = lane & 7;
-  const T* ga[IA];
-  const T* gb[IB];
-#pragma unroll
-  for (int q = 0; q < IA; ++q) {
-    const int row = (wave * IA + q) * 8 + drow;
-    ga[q] = A + (int64_t)row * lda + (dslot ^ swz(row)) * SL;
-  }
-#pragma unroll
-  for (int q = 0; q < IB; ++q) {
-    const int row = (wave * IB + q) * 8 + drow;
-    gb[q] = B + (int64_t)row * ldb + (dslot ^ swz(row)) * SL;
-  }
-  T* const la = As + wave * IA * RQ;
-  T* const lb = Bs + wave * IB * RQ;
-  const int sw = swz(l15);
-  const int a_off0 = (wr * WM + l15) * BK + ((2 * l4) ^ sw) * SL;
-  const int a_off1 = (wr * WM + l15) * BK + ((2 * l4 + 1) ^ sw) * SL;
-  const int b_off0 = (wc * WN + l15) * BK + ((2 * l4) ^ sw) * SL;
-  const int b_off1 = (wc * WN + l15) * BK + ((2 * l4 + 1) ^ sw) * SL;
-  const int KT = K / BK;
-#pragma unroll
-  for (int st = 0; st < 2; ++st) {
-    const int64_t ko = (int64_t)(st < KT ? st : KT - 1) * BK;
-#pragma unroll
-    for (int q = 0; q < IA; ++q) GPX_GLDS16(ga[q] + ko, la + st * S::A_STAGE + q * RQ);
-#pragma unroll
-    for (int q = 0; q < IB; ++q) GPX_GLDS16(gb[q] + ko, lb + st * S::B_STAGE + q * RQ);
-  }
-  constexpr int HALF = SL * MT * NT;
-  int buf = 0, nbuf = 2;  // buffer of step kt, buffer the DMA of step kt+2 goes to
-  for (int kt = 0; kt < KT; ++kt) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IA + IB) : "memory");
-    __builtin_amdgcn_s_barrier();
-    {
-      const int64_t ko = (int64_t)(kt + 2 < KT ? kt + 2 : KT - 1) * BK;
-#pragma unroll
-      for (int q = 0; q < IA; ++q) GPX_GLDS16(ga[q] + ko, la + nbuf * S::A_STAGE + q * RQ);
-#pragma unroll
-      for (int q = 0; q < IB; ++q) GPX_GLDS16(gb[q] + ko, lb + nbuf * S::B_STAGE + q * RQ);
-    }
-    const T* Ab = As + buf * S::A_STAGE;
-    const T* Bb = Bs + buf * S::B_STAGE;
-    slot_t a0[MT], b0[NT], a1[MT], b1[NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) a0[m] = *reinterpret_cast<const slot_t*>(Ab + a_off0 + m * 16 * BK);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) b0[n] = *reinterpret_cast<const slot_t*>(Bb + b_off0 + n * 16 * BK);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) a1[m] = *reinterpret_cast<const slot_t*>(Ab + a_off1 + m * 16 * BK);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) b1[n] = *reinterpret_cast<const slot_t*>(Bb + b_off1 + n * 16 * BK);
-#pragma unroll
-    for (int s = 0; s < SL; ++s)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = Num<T>::mfma(a0[m][s], b0[n][s], acc[m][n]);
-#pragma unroll
-    for (int s = 0; s < SL; ++s)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = Num<T>::mfma(a1[m][s], b1[n][s], acc[m][n]);
-    // DMA of step t+2 first (nothing waits for it soon), then the first-half fragments, then the
-    // second-half fragments inside the first quarter of the burst
-    __builtin_amdgcn_sched_group_barrier(0x20, IA + IB, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
-#pragma unroll
-    for (int i = 0; i < MT + NT; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x8, HALF / (2 * (MT + NT)), 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    buf = buf == 2 ? 0 : buf + 1;
-    nbuf = nbuf == 2 ? 0 : nbuf + 1;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail loads: nothing may land later
-  __builtin_amdgcn_s_barrier();
-}
-
 template <typename V4, int MT, int NT>
 __device__ __forceinline__ void zero_acc(V4 (&acc)[MT][NT]) {
 #pragma unroll
