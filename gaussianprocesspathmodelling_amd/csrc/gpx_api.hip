@@ -285,8 +285,7 @@ int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int
   if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (panel copy)");
   HIPCHK(h, hipEventRecord(e, s));
   HIPCHK(h, hipStreamWaitEvent(h->st4, e, 0));
-  HIPCHK(h, hipMemcpy2DAsync(Apanel, (size_t)ld * sizeof(T), P, (size_t)ldp * sizeof(T), (size_t)nbp * sizeof(T),
-                             (size_t)rows, hipMemcpyDeviceToDevice, h->st4));
+  launch_copy2d<T>(Apanel, ld, P, ldp, rows, nbp, h->st4);
   return GPX_OK;
 }
 
@@ -421,8 +420,7 @@ int solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld
     if (!e || !e_copy[set]) return fail(h, GPX_E_HIP, "hipEventCreate failed (block solve)");
     HIPCHK(h, hipEventRecord(e, s));
     HIPCHK(h, hipStreamWaitEvent(h->st4, e, 0));
-    HIPCHK(h, hipMemcpy2DAsync(XT + o, (size_t)ld * sizeof(T), Ts[set], (size_t)ldt * sizeof(T),
-                               (size_t)nbp * sizeof(T), (size_t)rows, hipMemcpyDeviceToDevice, h->st4));
+    launch_copy2d<T>(XT + o, ld, Ts[set], ldt, rows, nbp, h->st4);
     HIPCHK(h, hipEventRecord(e_copy[set], h->st4));
     return GPX_OK;
   };

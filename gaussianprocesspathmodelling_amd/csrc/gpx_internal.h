@@ -94,6 +94,9 @@ void launch_unpack_rhs(const T* YT, int64_t ld, int64_t n, int k, double scale, 
 template <typename T>
 void launch_var_rows(const T* VT, int64_t ld, int64_t m, int64_t ncols, double sf2, T* var,
                      hipStream_t st);
+// dst (rows x cols, ldd) = src (rows x cols, lds), streaming; cols * sizeof(T) multiple of 16, 16-byte aligned rows
+template <typename T>
+void launch_copy2d(T* dst, int64_t ldd, const T* src, int64_t lds, int64_t rows, int64_t cols, hipStream_t st);
 // A[i][i] = 1 for i < n
 template <typename T>
 void launch_set_diag_one_t(T* A, int64_t lda, int64_t n, hipStream_t st);
