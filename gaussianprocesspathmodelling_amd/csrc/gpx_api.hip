@@ -129,6 +129,12 @@ int fail(gpx_handle* h, int code, const char* msg) {
   return code;
 }
 
+#define LAUNCHCHK(h)                                                                                  \
+  do {                                                                                                \
+    if (take_launch_error())                                                                          \
+      return fail(h, GPX_E_ARG, "internal error: a triangular-solve operand was not 128-byte aligned"); \
+  } while (0)
+
 int ensure(gpx_handle* h, DevBuf& b, size_t bytes) {
   if (b.cap >= bytes && b.p) return GPX_OK;
   if (b.p) HIPCHK(h, hipFree(b.p));
@@ -604,6 +610,7 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   HIPCHK(h, hipMemcpyAsync(&h->logdet, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->st));
   HIPCHK(h, hipStreamSynchronize(h->st));
   HIPCHK(h, hipGetLastError());
+  LAUNCHCHK(h);
   collect_phases(h);
   *info = (hinfo == INT_MAX) ? 0 : (int64_t)hinfo;
   h->fitted = (*info == 0);
@@ -708,6 +715,7 @@ int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var
   }
   HIPCHK(h, hipStreamSynchronize(h->st));
   HIPCHK(h, hipGetLastError());
+  LAUNCHCHK(h);
   collect_phases(h);
   return GPX_OK;
 }
@@ -785,6 +793,7 @@ int lml_grad_impl(gpx_handle* h, double* lml, double* grad) {
   HIPCHK(h, hipMemcpyAsync(host, outv, (size_t)(2 * ntheta + 1) * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   HIPCHK(h, hipGetLastError());
+  LAUNCHCHK(h);
   collect_phases(h);
   for (int t = 0; t < ntheta; ++t) grad[t] = 0.5 * (host[ntheta + t] - (double)k * host[t]);
   *lml = -0.5 * host[2 * ntheta] - 0.5 * (double)k * h->logdet -
@@ -863,6 +872,7 @@ int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d,
   HIPCHK(h, hipMemcpyAsync(hn, rn, 24, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   HIPCHK(h, hipGetLastError());
+  LAUNCHCHK(h);
   collect_phases(h);
   tm.fit_total += tm.refine;
   if (hn[2] > 0) {
@@ -909,6 +919,7 @@ int mixed_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* va
   }
   HIPCHK(h, hipStreamSynchronize(st));
   HIPCHK(h, hipGetLastError());
+  LAUNCHCHK(h);
   collect_phases(h);
   (void)N;
   return GPX_OK;
@@ -1291,6 +1302,10 @@ int gpx_trsm(double* X, int64_t m, const double* L, int64_t nb) try {
   for (int64_t q = 0; q < nb / 64; ++q)
     launch_potf2_64(dL2 + q * 4096, 64, dW + q * 4096, q * 64, dInfo, st);
   launch_trsm_rlt<double>(dX, ldx, m, dL, ldl, dW, (int)nb, nullptr, 0, st);
+  if (take_launch_error()) {
+    rc = GPX_E_ARG;
+    goto done;
+  }
   TCHK(hipMemcpy2DAsync(X, (size_t)nb * 8, dX, (size_t)ldx * 8, (size_t)nb * 8, (size_t)m, hipMemcpyDeviceToHost, st));
   TCHK(hipStreamSynchronize(st));
   TCHK(hipGetLastError());

@@ -13,7 +13,7 @@
 // MFMA layouts (cdna_hip_programming.md §3), verified on hardware by gpx_mfma_probe:
 //   A lane l = A[l&15][l>>4],  B lane l = B[l>>4][l&15]   (both types)
 //   D reg r of lane l = D[(l>>4) + 4r][l&15]  for f64,   D[4(l>>4) + r][l&15]  for f32.
-#include <cstdio>
+#include <atomic>
 #include <cstdlib>
 
 #include "gpx_internal.h"
@@ -661,6 +661,11 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
 
 }  // namespace
 
+// A launcher that refuses its operands (the 128-byte row alignment trsm_rlt_kernel depends on)
+// launches nothing and raises this flag; every API entry point turns it into an error return.
+static std::atomic<int> g_launch_error{0};
+int take_launch_error() { return g_launch_error.exchange(0); }
+
 template <typename T>
 void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st) {
   hipLaunchKernelGGL(potf2_64_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, Winv, gidx0, info);
@@ -673,7 +678,7 @@ void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
   // builds ldx from ld_skew<T>(); a violation is a programming error in this library, caught
   // here before a silently stale read can happen.
   if (((uintptr_t)X | (uintptr_t)(ldx * (int64_t)sizeof(T))) % 128 != 0) {
-    fprintf(stderr, "libgpx: launch_trsm_rlt: X rows not 128-byte aligned (ldx = %lld)\n", (long long)ldx);
+    g_launch_error.store(1);  // reported by the API call in flight (take_launch_error)
     return;
   }
   hipLaunchKernelGGL(trsm_rlt_kernel<T>, dim3((unsigned)(rows / 64)), dim3(256), 0, st, X, ldx, L, ldl,
@@ -684,7 +689,7 @@ template <typename T>
 void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv, int q0, int q1, T* W,
                        int64_t ldw, hipStream_t st) {
   if (((uintptr_t)U | (uintptr_t)(ldu * (int64_t)sizeof(T))) % 128 != 0) {
-    fprintf(stderr, "libgpx: launch_inv_extend: U rows not 128-byte aligned\n");
+    g_launch_error.store(1);
     return;
   }
   hipLaunchKernelGGL(trsm_rlt_kernel<T>, dim3((unsigned)q1), dim3(256), 0, st, U, ldu, L, ldl, Winv, q0, q1,

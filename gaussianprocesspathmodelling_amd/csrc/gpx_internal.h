@@ -59,6 +59,8 @@ void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
 template <typename T>
 void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv, int q0, int q1, T* W,
                        int64_t ldw, hipStream_t st);
+// 1 if a launcher since the last call refused misaligned operands (and launched nothing); clears the flag
+int take_launch_error();
 // X (rows x nb, ldx) <- X * L^-1 (right, lower, no-transpose; descending blocks).
 template <typename T>
 void launch_trsm_rln(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, const T* Winv, int nb,
