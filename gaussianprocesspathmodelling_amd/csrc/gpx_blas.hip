@@ -122,23 +122,65 @@ __device__ __forceinline__ void gemm_tile_nn(const T* A, int64_t lda, const T* B
   }
 }
 
+// Diagnostic build only (-DGPX_STAMPS, tools/syrk_clock.py): one workgroup per launch stamps the
+// shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) around its
+// tile — their ratio is the clock the chip really holds inside the MFMA loop (sysfs can read up to
+// 10 % high; MI355X_MICROARCH.md "DVFS give-back" item 6).  Never in the shipped library.
+#ifdef GPX_STAMPS
+__device__ long long gpx_syrk_clock_buf[8];
+#endif
+
 // ---- C op= A * B^T --------------------------------------------------------------
 template <typename T, int BT, bool TRI, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
     int64_t ldb, int tiles_m, int tiles_n, int sh, int mask_lower, BcMask bc, int K) {
   __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
+#ifdef GPX_STAMPS
+  const long long cE = __builtin_amdgcn_s_memtime();
+#endif
   const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
   int ti, tj;
   if (!tile_coords<TRI>(lin, tiles_m, tiles_n, sh, mask_lower, bc, ti, tj)) return;
   typename Num<T>::v4 acc[BT / 32][BT / 32];
   zero_acc(acc);
   T* Ct = C + (int64_t)ti * BT * ldc + (int64_t)tj * BT;
+#ifdef GPX_STAMPS
+  const bool big = TRI && BT == 128 && K >= 512 && tiles_m >= 300 && threadIdx.x == 0;
+  const bool stamp = big && blockIdx.x == gridDim.x / 2;
+  const long long cA = big ? __builtin_amdgcn_s_memtime() : 0;
+  long long c0 = 0, r0 = 0;
+  if (stamp) {
+    c0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   gemm_tile_g<T, BT, BT>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc,
                          smem);
+#ifdef GPX_STAMPS
+  long long cL = 0;
+  if (big) {  // every workgroup of the big launches: sums of prologue / loop cycles and count
+    const long long now = __builtin_amdgcn_s_memtime();
+    atomicAdd(reinterpret_cast<unsigned long long*>(&gpx_syrk_clock_buf[5]), (unsigned long long)(now - cA));
+    atomicAdd(reinterpret_cast<unsigned long long*>(&gpx_syrk_clock_buf[6]), 1ull);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&gpx_syrk_clock_buf[7]), (unsigned long long)(cA - cE));
+    cL = now;
+  }
+  if (stamp) {
+    gpx_syrk_clock_buf[0] = cL - c0;
+    gpx_syrk_clock_buf[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    gpx_syrk_clock_buf[2] = K;
+    gpx_syrk_clock_buf[3] = c0 - cE;  // kernel entry -> first DMA issue
+  }
+#endif
   // (a software-pipelined epilogue — strips of C prefetched / kept in flight — measured
   //  0.5-1 % slower than this plain strip-by-strip one: it pushes the kernel to 256 VGPRs)
   store_tile<T, BT, BT, MODE>(Ct, ldc, acc);
+#ifdef GPX_STAMPS
+  if (big)  // epilogue issue (not completion), summed over the workgroups
+    atomicAdd(reinterpret_cast<unsigned long long*>(&gpx_syrk_clock_buf[4]),
+              (unsigned long long)(__builtin_amdgcn_s_memtime() - cL));
+#endif
 }
 
 // ---- C = A * W^T with W lower triangular (an explicit block inverse): panel / block solves -----
@@ -794,6 +836,9 @@ int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, i
 #ifdef GPX_STAMPS
 extern "C" int gpx_debug_read_stamps(long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(gpx_stamp_buf), (size_t)n * 8) == hipSuccess ? 0 : -2;
+}
+extern "C" int gpx_debug_read_syrk_clock(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gpx_syrk_clock_buf), 64) == hipSuccess ? 0 : -2;
 }
 #endif
 

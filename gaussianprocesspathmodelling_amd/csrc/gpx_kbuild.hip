@@ -56,10 +56,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const T* __restrict__ As, i
                                                     int tiles_n, T sf2, T diag_add, T* __restrict__ K,
                                                     int64_t ld) {
   const int d = (D > 0) ? D : d_rt;
-  // sized by the compile-time dimension: with the generic 2 x 16 KB (d up to 32) the LDS, not the
-  // registers, capped the d <= 3 instantiations at 5 workgroups per CU
-  __shared__ T xa[KT * (D > 0 ? D : MAXD)];
-  __shared__ T xb[KT * (D > 0 ? D : MAXD)];
+  __shared__ T xa[KT * MAXD];
+  __shared__ T xb[KT * MAXD];
   int ti, tj;
   if (SYM) {
     tri_coords((int64_t)blockIdx.x, ti, tj);

@@ -229,8 +229,11 @@ __host__ __device__ __forceinline__ int64_t xcd_chunk_id(int64_t bid, int64_t nb
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// Single-precision estimate + exact integer correction (no fp64 VALU in a prologue that runs beside
+// a partner saturating the fp64 MFMA pipe).
 __host__ __device__ __forceinline__ void tri_coords(int64_t t, int& ti, int& tj) {
-  int64_t i = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  int64_t i = (int64_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  if (i < 0) i = 0;
   while (i * (i + 1) / 2 > t) --i;
   while ((i + 1) * (i + 2) / 2 <= t) ++i;
   ti = (int)i;
