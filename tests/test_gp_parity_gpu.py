@@ -93,6 +93,22 @@ def test_predict_in_batches_is_identical(monkeypatch, batch):
         assert_parity(m2[:, c], v2, mr[:, c], vr, 1.5)
 
 
+def test_n32768_full_oracle():
+    """Half the bench size against the FULL CPU oracle (level-3 blocked Cholesky, ~30 s on the box's
+    16 CPUs, 8.6 GB): a driver-run parity point between C2 and the one-off full-size run of
+    tools/full_oracle_c3.py (profiles/r02_c3_full_oracle_parity.json)."""
+    N, M = 32768, 1024
+    X, y, Xs = synthetic_problem(N, 3, M)
+    ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0, chol="blocked").fit(X, y)
+    mr, vr = ref.predict(Xs)
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0) as gp:
+        mean, var = gp.fit(X, y).predict(Xs)
+        em, ev = assert_parity(mean, var, mr, vr, 1.5)
+        assert np.max(np.abs(gp.alpha_ - ref.alpha_)) <= 1e-7 * np.abs(ref.alpha_).max()
+        assert abs(gp.log_det_ - ref.log_det_) <= 1e-9 * abs(ref.log_det_)
+        print(f"N=32768 parity: mean {em:.2e} var {ev:.2e}")
+
+
 def test_multi_output_and_noise_flag():
     X, y, Xs = synthetic_problem(700, 3, 50, seed=11)
     Y = np.stack([y, np.cos(y), 2 * y - 1], axis=1)
