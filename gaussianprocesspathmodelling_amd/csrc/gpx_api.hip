@@ -213,7 +213,8 @@ struct InvWork {
   int64_t ldu = 0;
   int nbw = 0;
   hipStream_t aux = nullptr;
-  hipEvent_t ready = nullptr;  // recorded on aux when the inverse of the last enqueued block is complete
+  hipEvent_t ready = nullptr;      // recorded on aux when the inverse of the last enqueued block is complete
+  hipEvent_t copied[2] = {};       // copy-back of the panel last written into P buffer 0 / 1 (copy stream)
 };
 
 // diagonal block [o, o+nbp) on stream s.  iw != null: after the POTF2 of every 64-column step the
@@ -225,6 +226,12 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
   T* Wp = nullptr;
   if (iw) {
     Wp = iw->W + (o / iw->nbw) * (int64_t)iw->nbw * iw->nbw;
+    // the side stream starts behind everything already queued on s: the W block may live in a
+    // buffer that earlier work on s (or, through its waits, on other ranks) is still reading
+    hipEvent_t e0 = next_event(h);
+    if (!e0) return fail(h, GPX_E_HIP, "hipEventCreate failed (block inverse)");
+    HIPCHK(h, hipEventRecord(e0, s));
+    HIPCHK(h, hipStreamWaitEvent(iw->aux, e0, 0));
     HIPCHK(h, hipMemsetAsync(iw->U, 0, (size_t)iw->nbw * iw->ldu * sizeof(T), iw->aux));
     launch_set_diag_one_t<T>(iw->U, iw->ldu, nbp, iw->aux);
     HIPCHK(h, hipMemsetAsync(Wp, 0, (size_t)iw->nbw * iw->nbw * sizeof(T), iw->aux));
@@ -271,7 +278,7 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
 // before the factorisation is over: the trailing updates read P).  Without: the slab kernel.
 template <typename T>
 int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int64_t rows_main, int64_t nx,
-                        const T* Winv, T* P, int64_t ldp, hipStream_t s, InvWork<T>* iw) {
+                        const T* Winv, T* P, int64_t ldp, hipStream_t s, InvWork<T>* iw, int set) {
   T* Apanel = A + (o + nbp) * ld + o;
   const int64_t rows = rows_main + nx;
   if (rows <= 0) return GPX_OK;
@@ -281,6 +288,7 @@ int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int
   }
   const T* Wp = iw->W + (o / iw->nbw) * (int64_t)iw->nbw * iw->nbw;
   HIPCHK(h, hipStreamWaitEvent(s, iw->ready, 0));
+  if (iw->copied[set]) HIPCHK(h, hipStreamWaitEvent(s, iw->copied[set], 0));  // P[set] is about to be overwritten
   if (rows_main > 0)
     launch_gemm_nt<T>((rows_main % 128 == 0 && nbp % 128 == 0) ? 128 : 64, P, ldp, Apanel, ld, Wp, iw->nbw,
                       rows_main, nbp, nbp, 4, 1, s);
@@ -292,6 +300,9 @@ int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int
   HIPCHK(h, hipEventRecord(e, s));
   HIPCHK(h, hipStreamWaitEvent(h->st4, e, 0));
   launch_copy2d<T>(Apanel, ld, P, ldp, rows, nbp, h->st4);
+  iw->copied[set] = next_event(h);
+  if (!iw->copied[set]) return fail(h, GPX_E_HIP, "hipEventCreate failed (panel copy)");
+  HIPCHK(h, hipEventRecord(iw->copied[set], h->st4));
   return GPX_OK;
 }
 
@@ -315,7 +326,7 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     }
     {
       PhaseScope ps(h, &h->tm.chol_trsm, profile);
-      if ((rc = panel_solve_enqueue(h, A, ld, 0, nb0, n - nb0, nx, Winv, Pbuf[0], ldp, s0, iw))) return rc;
+      if ((rc = panel_solve_enqueue(h, A, ld, 0, nb0, n - nb0, nx, Winv, Pbuf[0], ldp, s0, iw, 0))) return rc;
     }
   }
   int step = 0;
@@ -351,7 +362,7 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       }
       {
         PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
-        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest, nx, Winv, Pn, ldp, s1, iw))) return rc;
+        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest, nx, Winv, Pn, ldp, s1, iw, (step + 1) & 1))) return rc;
       }
     }
     HIPCHK(h, hipEventRecord(e_panel, s1));

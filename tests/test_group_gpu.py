@@ -70,6 +70,25 @@ def test_group_predict_in_batches(monkeypatch, repl):
             assert np.max(np.abs(m1 - m2)) <= 1e-12 and np.max(np.abs(v1 - v2)) <= 1e-12
 
 
+def test_group_slab_panel_variant(monkeypatch):
+    """GPX_SHARD_DENSE_PANEL=0: the sharded panel solve by the slab kernel (64-block inverses) instead
+    of the dense product with the broadcast block inverse — same results."""
+    monkeypatch.setenv("GPX_NB_SHARD", "256")
+    X, y, Xs = synthetic_problem(2500, 3, 100, seed=12)
+    ref = OracleGP("matern52", 0.3, 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    out = []
+    for dense in ("1", "0"):
+        monkeypatch.setenv("GPX_SHARD_DENSE_PANEL", dense)
+        for repl in ("0", "1"):
+            monkeypatch.setenv("GPX_SHARD_REPLICATE", repl)
+            with GP("matern52", 0.3, 1.5, 1e-2, jitter=0.0, devices=[0, 0, 0]) as gp:
+                mean, var = gp.fit(X, y).predict(Xs)
+                check(mean, var, gp.alpha_, gp.log_det_, ref, mr, vr)
+                out.append(mean)
+    assert np.max(np.abs(out[0] - out[2])) <= 1e-10
+
+
 def test_devices_list_and_single_entry():
     X, y, Xs = synthetic_problem(900, 3, 40, seed=3)
     ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
