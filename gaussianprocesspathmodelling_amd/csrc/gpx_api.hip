@@ -8,13 +8,19 @@
 // np.linalg.norm at GPmap.py:120); the arithmetic follows oracle/gp_oracle.py
 // (R&W Alg. 2.1).
 //
-// Data layout in HBM (all fp64, row-major):
-//   K / L   [Npad][ld]   ld = Npad + 16 (skewed against power-of-two strides); only the
-//                        lower triangle is referenced; rows/cols >= N are identity
+// Data layout in HBM (element type T = double, or float for the fp32 / mixed handles; row-major):
+//   K / L   [Npad+64][ld]  ld = Npad + one 128-byte line (skew against power-of-two strides; rows
+//                          128-byte aligned); only the lower triangle is referenced; rows/cols >= N
+//                          are identity; rows [Npad, Npad+64) carry the right-hand sides ("bordered")
 //   Winv    [Npad/64][64][64]   inverses of the 64x64 diagonal blocks of L
-//   P       [Npad][nb+16]       compact copy of the current panel (SYRK operand)
-//   YT      [64][ld]            right-hand sides / alpha, transposed (row r = target r)
-//   VT      [Mpad][ld]          K* and, after the forward solve, V^T
+//   Wblk    [Npad/nb][nb][nb]   explicit inverses of the nb x nb diagonal blocks (panel / block solves
+//                               are dense products with them), built beside the factorisation
+//   P       2 x [Npad+64][nb+skew]  compact copies of the current / next panel (SYRK operand)
+//   VT      [MB][ld]            K* and, after the forward solve, V^T — one batch of MB <= 8192 query points
+//   ZT      [Npad][ld]          L^-T, on demand, for gpx_lml_grad
+// Streams: st (main), st2 (look-ahead: diagonal block + panel solve of the next panel, high
+// priority), st3 (side: block-inverse extension), st4 (copies of solved panels / blocks back
+// into their matrices).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
