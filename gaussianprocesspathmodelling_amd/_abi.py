@@ -67,6 +67,7 @@ SIGNATURES = {
     "gpx_get_alpha": (C.c_int, [_P, _P]),
     "gpx_lml_grad": (C.c_int, [_P, _PD, _PD]),
     "gpx_logdet": (C.c_int, [_P, _PD]),
+    "gpx_release_scratch": (C.c_int, [_P]),
     "gpx_get_timings": (C.c_int, [_P, C.POINTER(GpxTimings)]),
     "gpx_comm_unique_id": (C.c_int, [_P]),
     "gpx_comm_init": (C.c_int, [_P, _P]),

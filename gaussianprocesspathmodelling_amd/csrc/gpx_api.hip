@@ -1151,6 +1151,25 @@ int gpx_lml_grad(gpx_handle* h, double* lml, double* grad) try {
 }
 GPX_CATCH_ALL
 
+int gpx_release_scratch(gpx_handle* h) try {
+  if (!h) return GPX_E_ARG;
+  std::vector<gpx_handle*> hs;
+  if (h->group)
+    hs = h->group->members;
+  else
+    hs.push_back(h);
+  for (gpx_handle* m : hs) {
+    HIPCHK(h, hipSetDevice(m->cfg.device));
+    for (hipStream_t sx : {m->st, m->st2, m->st3, m->st4})
+      if (sx) HIPCHK(h, hipStreamSynchronize(sx));
+    for (DevBuf* b : {&m->ZT, &m->gpart, &m->VT, &m->Tsol, &m->Q, &m->Qs, &m->MT, &m->Sv, &m->Q64, &m->Qs64, &m->Q32,
+                      &m->M64, &m->GatherS, &m->GatherR, &m->outM, &m->outV})
+      release(*b);
+  }
+  return GPX_OK;
+}
+GPX_CATCH_ALL
+
 int gpx_logdet(gpx_handle* h, double* out) try {
   if (!h) return GPX_E_ARG;
   if (!h->fitted || !out) return fail(h, GPX_E_ARG, "gpx_logdet: no fit or null output");

@@ -262,6 +262,11 @@ class GP:
             var += self.noise
         return mean, var
 
+    def release_scratch(self):
+        """Free the device buffers only the next ``predict`` / ``lml_gradient`` would use (V^T batch,
+        L^-T, partial sums); the fit stays valid.  Buffers otherwise stay allocated for reuse."""
+        self._check(self._lib.gpx_release_scratch(self._h))
+
     @property
     def alpha_(self):
         if not self._fitted:

@@ -130,6 +130,12 @@ int gpx_get_alpha(gpx_handle* h, void* out /* (N,k) host */);
  * buffer; K^-1 itself is never stored.  fp64, single-GPU handles. */
 int gpx_lml_grad(gpx_handle* h, double* lml, double* grad);
 int gpx_logdet(gpx_handle* h, double* out);
+/* Frees what only the NEXT predict / gradient call would use (the V^T batch, the L^-T buffer of
+ * gpx_lml_grad, per-tile partials, compact block buffers); the fit itself (factor, alpha, block
+ * inverses) stays valid.  Buffers grow on demand and are otherwise kept for reuse: call this
+ * between a gradient and a large predict when N is close to what the card holds (at N = 131072 the
+ * factor and L^-T are 137 GB each). */
+int gpx_release_scratch(gpx_handle* h);
 int gpx_get_timings(gpx_handle* h, gpx_timings* out);
 
 /* ---- row-block sharding over RCCL ------------------------------ */

@@ -139,6 +139,20 @@ def test_max_targets_share_one_factorisation():
         GP("rbf", 0.3).fit(X, np.zeros((900, 65)))
 
 
+def test_release_scratch_keeps_the_fit():
+    torch = pytest.importorskip("torch")
+    X, y, Xs = synthetic_problem(3000, 3, 500, seed=6)
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0) as gp:
+        m1, v1 = gp.fit(X, y).predict(Xs)
+        l1, g1 = gp.lml_gradient()
+        free_before = torch.cuda.mem_get_info(0)[0]
+        gp.release_scratch()
+        assert torch.cuda.mem_get_info(0)[0] > free_before        # L^-T, V^T, ... are gone
+        m2, v2 = gp.predict(Xs)
+        l2, g2 = gp.lml_gradient()
+        assert np.array_equal(m1, m2) and np.array_equal(v1, v2) and l1 == l2 and np.array_equal(g1, g2)
+
+
 def test_refit_reuses_handle_and_permutation_invariance():
     X, y, Xs = synthetic_problem(640, 2, 40, seed=2)
     with GP("matern52", 0.35, 1.0, 1e-2) as gp:
