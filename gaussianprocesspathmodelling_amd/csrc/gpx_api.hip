@@ -1450,6 +1450,54 @@ done:
 }
 GPX_CATCH_ALL
 
+// The tile engine alone, operands resident: C (n x n) op= A (n x k) A'(n x k)^T on zero-filled device
+// buffers, `iters` back-to-back launches after one warm-up; *ms = mean launch time.
+extern "C++" {
+template <typename T>
+int gemm_bench_t(int64_t n, int64_t k, int32_t lower, int32_t mode, int32_t iters, double* ms) {
+  Scratch sc;
+  if (!sc.ok) return GPX_E_HIP;
+  hipStream_t st = sc.h.st;
+  const int64_t ldc = n + ld_skew<T>(), lda = k + ld_skew<T>();
+  T *dC = nullptr, *dA = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float t = 0.f;
+  int rc = GPX_OK;
+  TCHK(hipMalloc(&dC, (size_t)n * ldc * sizeof(T)));
+  TCHK(hipMalloc(&dA, (size_t)2 * n * lda * sizeof(T)));
+  TCHK(hipMemsetAsync(dC, 0, (size_t)n * ldc * sizeof(T), st));
+  TCHK(hipMemsetAsync(dA, 0, (size_t)2 * n * lda * sizeof(T), st));
+  TCHK(hipEventCreate(&e0));
+  TCHK(hipEventCreate(&e1));
+  launch_gemm_nt<T>(128, dC, ldc, dA, lda, dA + n * lda, lda, n, n, k, lower, mode, st);
+  TCHK(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i)
+    launch_gemm_nt<T>(128, dC, ldc, dA, lda, dA + n * lda, lda, n, n, k, lower, mode, st);
+  TCHK(hipEventRecord(e1, st));
+  TCHK(hipStreamSynchronize(st));
+  TCHK(hipGetLastError());
+  TCHK(hipEventElapsedTime(&t, e0, e1));
+  *ms = (double)t / iters;
+done:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (dC) (void)hipFree(dC);
+  if (dA) (void)hipFree(dA);
+  return rc;
+}
+}  // extern "C++"
+
+int gpx_debug_gemm_bench(int32_t dtype, int64_t n, int64_t k, int32_t lower, int32_t mode, int32_t iters,
+                         double* ms_per_launch) try {
+  if (!ms_per_launch || n <= 0 || n % 128 || k <= 0 || k % 32 || iters <= 0 || (lower != 0 && lower != 1) ||
+      (mode != 0 && mode != 1) || n > 131072 || k > 8192)
+    return GPX_E_ARG;
+  if (dtype == GPX_F64) return gemm_bench_t<double>(n, k, lower, mode, iters, ms_per_launch);
+  if (dtype == GPX_F32) return gemm_bench_t<float>(n, k, lower, mode, iters, ms_per_launch);
+  return GPX_E_ARG;
+}
+GPX_CATCH_ALL
+
 int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t tpb, int32_t c, int32_t* out,
                        int64_t cap, int64_t* count) try {
   if (!out || !count || tm <= 0 || cap <= 0 || (kind != 0 && kind != 1)) return GPX_E_ARG;

@@ -262,6 +262,34 @@ class GP:
             var += self.noise
         return mean, var
 
+    # -- checkpoint / resume (optional get_state) ------------------------------
+    def get_state(self):
+        """Plain-data description of the model (JSON-serialisable): kernel, hyper-parameters,
+        dtype, panel width and, once fitted, the jitter that was needed and the log-determinant.
+        The training data and the factor are NOT included — the factor is N^2 numbers the GPU
+        rebuilds faster than storage returns them, and the path is deterministic:
+        ``GP.from_state(s).fit(X, y)`` reproduces alpha, mean and variance bit for bit (tested),
+        so a hyper-parameter search is resumed by saving this after every ``optimize`` step."""
+        st = {"format": 1, "kernel": self.kernel, "lengthscale": [float(v) for v in self.lengthscale],
+              "variance": self.variance, "noise": self.noise, "jitter": self.jitter, "dtype": self.dtype,
+              "block": self.block, "max_tries": self.max_tries}
+        if self._fitted:
+            st["fitted"] = {"N": int(self._N), "d": int(self._d), "k": int(self._k),
+                            "jitter_used": float(self.jitter_used_), "log_det": float(self.log_det_)}
+        return st
+
+    @classmethod
+    def from_state(cls, state, **overrides):
+        """A fresh, unfitted model from :meth:`get_state` output; ``overrides`` are passed to the
+        constructor (``device=``, ``devices=``, ``profile=`` ... are not part of the state)."""
+        if state.get("format") != 1:
+            raise ValueError("not a GP state of this library (format 1)")
+        kw = {k: state[k] for k in ("kernel", "variance", "noise", "jitter", "dtype", "block", "max_tries")}
+        ls = state["lengthscale"]
+        kw["lengthscale"] = ls[0] if len(ls) == 1 else ls
+        kw.update(overrides)
+        return cls(**kw)
+
     def release_scratch(self):
         """Free the device buffers only the next ``predict`` / ``lml_gradient`` would use (V^T batch,
         L^-T, partial sums); the fit stays valid.  Buffers otherwise stay allocated for reuse."""

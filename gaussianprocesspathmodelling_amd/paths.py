@@ -233,3 +233,106 @@ def kmeans(trajs, k, too_close=MIN_TRAVEL, init_keys=None, rng=None, movement_st
         if moved < movement_stop:
             return clusters
     raise RuntimeError("k-means did not converge")
+
+
+# ---- one GP per path cluster (independent replicas) ---------------------------------------------
+class PathModel:
+    """GP model of one cluster of paths: inputs (by default the time stamp, mapped to [0, 1]) ->
+    (x, y) as two targets sharing ONE Cholesky factor.  Targets are
+    standardised per column before the fit (the GP prior has zero mean) and mapped back by
+    :meth:`predict`."""
+
+    def __init__(self, gp, keys, in_lo, in_span, y_mean, y_std, inputs, targets):
+        self.gp, self.keys = gp, list(keys)
+        self.in_lo, self.in_span, self.y_mean, self.y_std = in_lo, in_span, y_mean, y_std
+        self.inputs, self.targets = tuple(inputs), tuple(targets)
+
+    def predict(self, q, return_var=True, include_noise=False):
+        """Posterior at raw (un-normalised) inputs ``q`` (M,) or (M, d): mean (M, k) in the
+        targets' own units and, with ``return_var``, the variance (M, k) per target."""
+        q = np.asarray(q, dtype=np.float64)
+        q = q.reshape(-1, 1) if q.ndim == 1 else q
+        if q.ndim != 2 or q.shape[1] != len(self.inputs):
+            raise ValueError(f"queries must be (M,) or (M, {len(self.inputs)})")
+        qn = np.ascontiguousarray((q - self.in_lo) / self.in_span)
+        out = self.gp.predict(qn, return_var=return_var, include_noise=include_noise)
+        mean = (out[0] if return_var else out).reshape(len(qn), -1) * self.y_std + self.y_mean
+        if not return_var:
+            return mean
+        return mean, out[1][:, None] * (self.y_std ** 2)[None, :]
+
+    def close(self):
+        self.gp.close()
+
+
+def fit_path_models(trajs, clusters, inputs=("t",), targets=("x", "y"), devices=None, optimize=False,
+                    lengthscale=0.25, variance=1.0, noise=0.05, **gp_kwargs):
+    """One exact GP per cluster of ``clusters`` = {cluster id: [path ids]} — what
+    :func:`kmeans` (``kmeansclustering``, GPmap.py:36-93) returns — modelling the cluster's paths
+    as (x(t), y(t)); the modelling step the reference's title names and its clustering prepares
+    (the reference itself stops after the clustering, GPmap.py:220).
+
+    The clusters are independent problems, so they run as REPLICAS (SURVEY.md §8e "Replicas-only
+    parts"): cluster i is fitted on ``devices[i % len(devices)]`` (an int n = devices 0..n-1;
+    default: the current device), one host thread per device, no data-path collective.  With
+    ``optimize`` the hyper-parameters of each model are fitted by :meth:`GP.optimize` (analytic
+    gradient) first.  Returns {cluster id: :class:`PathModel`}; empty clusters are skipped."""
+    from concurrent.futures import ThreadPoolExecutor
+    from .gp import GP
+    if devices is None:
+        devs = [None]
+    elif isinstance(devices, (int, np.integer)):
+        if devices < 1:
+            raise ValueError("devices must be >= 1")
+        devs = list(range(int(devices)))
+    else:
+        devs = [int(v) for v in devices]
+        if not devs:
+            raise ValueError("devices must not be empty")
+    known = set(trajs.keys())
+    jobs = []
+    for cid, keys in clusters.items():
+        keys = list(keys)
+        if not keys:
+            continue
+        missing = [q for q in keys if q not in known]
+        if missing:
+            raise KeyError(f"cluster {cid!r} names unknown paths {missing[:3]}")
+        jobs.append((cid, keys))
+
+    def fit_one(slot, cid, keys):
+        X, Y, (lo, span) = to_gp_inputs(trajs, keys, inputs=inputs, targets=targets, normalise=True)
+        mu = Y.mean(axis=0)
+        sd = Y.std(axis=0)
+        sd = np.where(sd > 0, sd, 1.0)
+        Yn = np.ascontiguousarray((Y - mu) / sd)
+        gp = GP(lengthscale=lengthscale, variance=variance, noise=noise, device=devs[slot % len(devs)],
+                **gp_kwargs)
+        try:
+            if optimize:
+                gp.optimize(X, Yn)                 # leaves the model fitted at the best point
+            else:
+                gp.fit(X, Yn)
+        except Exception:
+            gp.close()
+            raise
+        return cid, PathModel(gp, keys, lo, span, mu, sd, inputs, targets)
+
+    by_dev = [[] for _ in devs]                    # one worker per device, its clusters in order
+    for i, (cid, keys) in enumerate(jobs):
+        by_dev[i % len(devs)].append((i, cid, keys))
+    models = {}
+    with ThreadPoolExecutor(max_workers=len(devs)) as pool:
+        futs = [pool.submit(lambda lst=lst: [fit_one(i, c, k) for i, c, k in lst]) for lst in by_dev if lst]
+        err = None
+        for f in futs:
+            try:
+                for cid, m in f.result():
+                    models[cid] = m
+            except Exception as e:                  # keep collecting so every handle gets closed
+                err = err or e
+        if err is not None:
+            for m in models.values():
+                m.close()
+            raise err
+    return {cid: models[cid] for cid, _ in jobs}

@@ -208,6 +208,13 @@ int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t 
 int gpx_debug_local_hub(int32_t P, int32_t rounds, int32_t abort_rank, int32_t abort_round,
                         int32_t* completed);
 
+/* Diagnostics: the dense tile engine alone, operands resident in HBM (zero-filled): C (n,n) -= / =
+ * A (n,k) B(n,k)^T, lower != 0: the triangular (SYRK-shaped) launch of the trailing update; mode 0:
+ * C -= (atomic epilogue), 1: C = (plain stores).  dtype GPX_F64 / GPX_F32; n multiple of 128,
+ * k of 32.  One warm-up launch, then the mean of `iters` back-to-back launches in ms. */
+int gpx_debug_gemm_bench(int32_t dtype, int64_t n, int64_t k, int32_t lower, int32_t mode, int32_t iters,
+                         double* ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,3 +80,15 @@ def test_to_gp_inputs(g4):
     X3, Y0, _ = gpaths.to_gp_inputs(t, keys=t.keys()[:2], inputs=("t", "x", "y"), targets=(), normalise=False)
     assert X3.shape == (66, 3) and Y0.shape == (66, 0)
     assert np.array_equal(X3[:33, 1], t.pathdict[t.keys()[0]].xs)
+
+
+def test_fit_path_models_argument_checks(g4):
+    """Host-side checks of the per-cluster model front end run before any GPU call."""
+    t = gpaths.read_csv(g4["csv"])
+    with pytest.raises(KeyError):
+        gpaths.fit_path_models(t, {0: ["no-such-path"]})
+    with pytest.raises(ValueError):
+        gpaths.fit_path_models(t, {0: t.keys()[:2]}, devices=[])
+    with pytest.raises(ValueError):
+        gpaths.fit_path_models(t, {0: t.keys()[:2]}, devices=0)
+    assert gpaths.fit_path_models(t, {0: [], 1: []}) == {}

@@ -59,3 +59,80 @@ def test_kmeans_separates_obvious_groups_and_feeds_the_gp(g4):
     with GP("matern52", 0.3, variance=float(Y.var()), noise=1e-4 * float(Y.var())) as gp:
         mean, var = gp.fit(X, Y - Y.mean(0)).predict(X[:5])
         assert mean.shape == (5, 2) and np.all(np.isfinite(mean)) and np.all(var >= 0)
+
+
+def _synthetic_groups(n_groups=3, per_group=7, seed=5):
+    """Paths of 33 points in a few spatial groups: smooth curves + per-path offsets + noise."""
+    rng = np.random.default_rng(seed)
+    t = gpaths.Trajectories()
+    truth = {}
+    tt = np.arange(33, dtype=float) * 40.0
+    for g in range(n_groups):
+        cx, cy = 4000.0 * g, 2500.0 * (g % 2)
+        for p in range(per_group):
+            tr = gpaths.Trajectory()
+            ox, oy = rng.normal(0, 60, 2)
+            for i in range(33):
+                s = i / 32.0
+                tr.add_point(tt[i], cx + ox + 1500.0 * s + 200.0 * np.sin(3 * s + g) + rng.normal(0, 15),
+                             cy + oy + 900.0 * s * s + rng.normal(0, 15))
+            key = f"G{g}P{p}"
+            t.add_trajectory(key, tr)
+            truth.setdefault(g, []).append(key)
+    return t, truth
+
+
+def _oracle_model(t, keys, kernel, ls, var, noise, q):
+    X, Y, (lo, span) = gpaths.to_gp_inputs(t, keys)
+    mu, sd = Y.mean(0), Y.std(0)
+    o = gp_oracle.OracleGP(kernel, ls, var, noise, jitter=1e-10 * var).fit(X, (Y - mu) / sd)
+    m, v = o.predict((q.reshape(-1, 1) - lo) / span)
+    return m * sd + mu, v[:, None] * sd ** 2
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+def test_one_gp_per_cluster_matches_the_oracle(devices):
+    """fit_path_models: k-means clusters -> one two-target GP each; replicas dealt over the
+    device list (here two worker threads sharing GPU 0), each checked against the CPU oracle."""
+    t, truth = _synthetic_groups()
+    clusters = gpaths.kmeans(t, 3, init_keys=["G0P0", "G1P0", "G2P0"])
+    assert sorted(sorted(v) for v in clusters.values()) == sorted(sorted(v) for v in truth.values())
+    models = gpaths.fit_path_models(t, clusters, devices=devices, kernel="matern52", lengthscale=0.3,
+                                    variance=1.0, noise=0.02)
+    try:
+        assert list(models) == list(clusters)
+        q = np.linspace(-50.0, 1400.0, 57)           # raw time stamps, inside and outside the data
+        for cid, m in models.items():
+            assert m.keys == clusters[cid]
+            mean, var = m.predict(q)
+            om, ov = _oracle_model(t, clusters[cid], "matern52", 0.3, 1.0, 0.02, q)
+            assert mean.shape == (57, 2) and var.shape == (57, 2)
+            assert np.max(np.abs(mean - om)) <= 1e-6 * np.max(np.abs(om))
+            assert np.max(np.abs(var - ov)) <= 1e-6 * np.max(np.abs(ov))
+            # mean only = K* alpha, with the variance = V^T z: two summation orders of the same mean
+            assert np.max(np.abs(m.predict(q, return_var=False) - mean)) <= 1e-8 * np.max(np.abs(mean))
+            # the model follows its own cluster: the posterior mean stays within the spread of the paths
+            arr = t.as_array(clusters[cid])
+            mid, _ = m.predict(arr[0, :, 0])
+            assert np.max(np.abs(mid - arr[:, :, 1:3].mean(0))) < 150.0
+    finally:
+        for m in models.values():
+            m.close()
+
+
+def test_path_models_with_fitted_hyperparameters():
+    t, truth = _synthetic_groups(n_groups=2, per_group=6, seed=9)
+    clusters = {g: keys for g, keys in truth.items()}
+    clusters["empty"] = []                          # skipped
+    base = gpaths.fit_path_models(t, clusters, lengthscale=0.05, noise=0.5)
+    opt = gpaths.fit_path_models(t, clusters, lengthscale=0.05, noise=0.5, optimize=True)
+    try:
+        assert list(opt) == [0, 1]
+        for cid in opt:
+            X, Y, _ = gpaths.to_gp_inputs(t, clusters[cid])
+            Yn = (Y - Y.mean(0)) / Y.std(0)
+            assert opt[cid].gp.log_marginal_likelihood(Yn) > base[cid].gp.log_marginal_likelihood(Yn) + 1.0
+            assert opt[cid].gp.noise < 0.5            # the data are far less noisy than the start says
+    finally:
+        for m in list(base.values()) + list(opt.values()):
+            m.close()
