@@ -99,6 +99,7 @@ struct gpx_handle {
   DevBuf X64, Y64, Xs64, A64, R64, X32, Y32, RT32, Q64, Qs64, Q32, M64, rn;
   int refine = 3;
   DevBuf Tsol;       // predict: compact solved blocks of V^T (2 x batch x (nb + skew))
+  DevBuf ZTloc, ZTpack;  // sharded gradient: own row blocks of L^-T (stacked), one packed block in flight
   DevBuf Wblk, Ublk; // explicit inverses of the nb x nb diagonal blocks of L ([Npad/nb][nb][nb]) + scratch
   int nbw = 0;       // block width of Wblk (0: not built)
   int nb_shard = 512;  // distribution block = panel width of the sharded factorisation (chosen per fit)
@@ -737,32 +738,42 @@ int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var
   return GPX_OK;
 }
 
-// ZT (n x n, ld; the identity on entry) <- ZT * L^-T = L^-T, the forward substitution of
-// solve_fwd_enqueue restricted to the rows that are not structurally zero: row r of ZT is zero
-// left of column r, so column block [o, o+nb) only involves rows [0, o+nb).  N^3/3 flops,
-// same STRIP / REST look-ahead.
+// ZT <- ZT * L^-T = L^-T restricted to the rows this rank owns: the forward substitution of
+// solve_fwd_enqueue on the rows that are not structurally zero.  Row r of L^-T is zero left of
+// column r and the rows are independent (a right-hand multiplication), so the row blocks of
+// height nb are dealt block-cyclically over P ranks with no exchange: rank `rank` keeps its blocks
+// b = rank, rank + P, ... stacked in ZT (local block j = global block j P + rank, the identity at
+// columns [b nb, b nb + nb) on entry), and column block [o, o + nb) only involves the local rows of
+// the blocks below o / nb — a prefix of the stack.  P = 1: the whole L^-T in place, N^3/3 flops;
+// same STRIP / REST look-ahead as the factorisation.
 int trtri_enqueue(gpx_handle* h, double* ZT, const double* L, int64_t ld, int64_t n, int nb,
-                  const double* Winv) {
+                  const double* Winv, int P, int rank) {
   hipStream_t s0 = h->st, s1 = h->st2;
-  launch_trsm_rlt<double>(ZT, ld, std::min<int64_t>(nb, n), L, ld, Winv, (int)std::min<int64_t>(nb, n), nullptr, 0, s0);
+  auto rows_below = [&](int64_t t) -> int64_t {  // local rows of the own blocks with index < t / nb
+    const int64_t q = t / nb;
+    return q > rank ? (q - rank + P - 1) / P * nb : 0;
+  };
+  auto own = [&](int64_t t) { return (int)((t / nb) % P) == rank; };
+  if (own(0))
+    launch_trsm_rlt<double>(ZT, ld, std::min<int64_t>(nb, n), L, ld, Winv, (int)std::min<int64_t>(nb, n), nullptr, 0, s0);
   for (int64_t o = 0; o < n; o += nb) {
     const int nbp = (int)std::min<int64_t>(nb, n - o);
     const int64_t t0 = o + nbp, ntrail = n - t0;
     if (ntrail <= 0) break;
     const int nbn = (int)std::min<int64_t>(nb, ntrail);
     const int64_t nrest = ntrail - nbn;
-    const int64_t R = t0;  // rows [0, t0) of column block o are non-zero
+    const int64_t R = rows_below(t0);                    // local rows that are non-zero in column block o
+    const int64_t Rn = R + (own(t0) ? nbn : 0);          // ... plus the identity rows of block t0 / nb
     const int tl = (R % 128 == 0 && nbn % 128 == 0 && nrest % 128 == 0) ? 128 : 64;
-    launch_gemm_nt<double>(tl, ZT + t0, ld, ZT + o, ld, L + t0 * ld + o, ld, R, nbn, nbp, 0, 0, s0);  // STRIP
+    if (R > 0) launch_gemm_nt<double>(tl, ZT + t0, ld, ZT + o, ld, L + t0 * ld + o, ld, R, nbn, nbp, 0, 0, s0);  // STRIP
     hipEvent_t e_strip = next_event(h), e_blk = next_event(h);
     if (!e_strip || !e_blk) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
     HIPCHK(h, hipEventRecord(e_strip, s0));
     HIPCHK(h, hipStreamWaitEvent(s1, e_strip, 0));
-    // block column t0: rows [0, t0) just updated plus the identity rows [t0, t0 + nbn) of its own block
-    launch_trsm_rlt<double>(ZT + t0, ld, t0 + nbn, L + t0 * ld + t0, ld, Winv + (t0 / KB) * (KB * KB), nbn,
-                            nullptr, 0, s1);
+    if (Rn > 0)
+      launch_trsm_rlt<double>(ZT + t0, ld, Rn, L + t0 * ld + t0, ld, Winv + (t0 / KB) * (KB * KB), nbn, nullptr, 0, s1);
     HIPCHK(h, hipEventRecord(e_blk, s1));
-    if (nrest > 0)  // REST
+    if (nrest > 0 && R > 0)  // REST
       launch_gemm_nt<double>(tl, ZT + t0 + nbn, ld, ZT + o, ld, L + (t0 + nbn) * ld + o, ld, R, nrest, nbp, 0, 0,
                              s0);
     HIPCHK(h, hipStreamWaitEvent(s0, e_blk, 0));
@@ -770,17 +781,33 @@ int trtri_enqueue(gpx_handle* h, double* ZT, const double* L, int64_t ld, int64_
   return GPX_OK;
 }
 
+// Gradient of the log marginal likelihood.  Sharded handles (replicated factor: every rank holds
+// the whole L): L^-T in row blocks dealt over the ranks (no exchange), one all-gather of its
+// non-zero part (block b: rows x columns >= b nb, packed), the fused K^-1 trace pass with the
+// tile groups dealt over the ranks, one all-reduce of ntheta sums.  alpha and its quadratic
+// form are replicated work (O(N^2)), identical on every rank.
 int lml_grad_impl(gpx_handle* h, double* lml, double* grad) {
   const int64_t N = h->N, Npad = h->Npad, ld = h->ld;
   const int d = h->d, k = h->k, ntheta = h->n_ls + 2, ard = h->n_ls > 1;
+  Comm* cm = h->comm;
+  const int P = cm ? cm->world : 1, rank = cm ? cm->rank : 0;
+  const int nb = h->nb_pred;
   gpx_timings& tm = h->tm;
   tm.grad_trtri = tm.grad_trace = tm.grad_total = 0;
   const int64_t s1n = kinv_trace_slots(Npad), s2n = alpha_quad_slots(Npad);
+  const int64_t nblk = (Npad + nb - 1) / nb;
+  int64_t nloc = 0;  // rows of the own blocks (the last block may be ragged)
+  for (int64_t b = rank; b < nblk; b += P) nloc += std::min<int64_t>(nb, Npad - b * nb);
   int rc;
   if ((rc = ensure_alpha<double>(h))) return rc;
   if ((rc = ensure(h, h->ZT, (size_t)Npad * ld * 8))) return rc;
+  if (P > 1) {
+    if ((rc = ensure(h, h->ZTloc, (size_t)std::max<int64_t>(nloc, 1) * ld * 8))) return rc;
+    if ((rc = ensure(h, h->ZTpack, (size_t)nb * Npad * 8))) return rc;
+  }
   if ((rc = ensure(h, h->gpart, (size_t)((s1n + s2n) * ntheta + 2 * ntheta + 1) * 8))) return rc;
   double* ZT = (double*)h->ZT.p;
+  double* Zl = P > 1 ? (double*)h->ZTloc.p : ZT;
   double* part1 = (double*)h->gpart.p;
   double* part2 = part1 + s1n * ntheta;
   double* outv = part2 + s2n * ntheta;  // [ntheta] K^-1 sums, [ntheta] alpha sums, [1] y . alpha
@@ -789,22 +816,40 @@ int lml_grad_impl(gpx_handle* h, double* lml, double* grad) {
     PhaseScope total(h, &tm.grad_total);
     {
       PhaseScope ps(h, &tm.grad_trtri);
-      HIPCHK(h, hipMemsetAsync(ZT, 0, (size_t)Npad * ld * 8, st));
-      launch_set_diag_one(ZT, ld, Npad, st);
-      if ((rc = trtri_enqueue(h, ZT, (const double*)h->Lfac, ld, Npad, h->nb_pred, (const double*)h->Winv.p)))
+      HIPCHK(h, hipMemsetAsync(Zl, 0, (size_t)(P > 1 ? nloc : Npad) * ld * 8, st));
+      if (P == 1) {
+        launch_set_diag_one(ZT, ld, Npad, st);
+      } else {
+        int64_t j = 0;
+        for (int64_t b = rank; b < nblk; b += P, ++j)
+          launch_set_diag_one(Zl + j * nb * ld + b * nb, ld, std::min<int64_t>(nb, Npad - b * nb), st);
+      }
+      if ((rc = trtri_enqueue(h, Zl, (const double*)h->Lfac, ld, Npad, nb, (const double*)h->Winv.p, P, rank)))
         return rc;
+      if (P > 1) {  // all-gather: block b from rank b % P, only the columns right of its zeros
+        double* pack = (double*)h->ZTpack.p;
+        HIPCHK(h, hipMemsetAsync(ZT, 0, (size_t)Npad * ld * 8, st));
+        for (int64_t b = 0; b < nblk; ++b) {
+          const int64_t r0 = b * nb, hb = std::min<int64_t>(nb, Npad - r0), w = Npad - r0;
+          const int root = (int)(b % P);
+          if (root == rank) launch_copy2d<double>(pack, w, Zl + (b / P) * nb * ld + r0, ld, hb, w, st);
+          if ((rc = cm->bcast(h, pack, (size_t)(hb * w), root, st))) return rc;
+          launch_copy2d<double>(ZT + r0 * ld + r0, ld, pack, w, hb, w, st);
+        }
+      }
     }
     {
       PhaseScope ps(h, &tm.grad_trace);
-      HIPCHK(h, hipMemsetAsync(part1, 0, (size_t)(s1n + s2n) * ntheta * 8, st));  // ragged-edge slots write nothing
+      HIPCHK(h, hipMemsetAsync(part1, 0, (size_t)(s1n + s2n) * ntheta * 8, st));  // ragged-edge / other ranks' slots write nothing
       launch_kinv_trace(h->cfg.kernel, ZT, ld, Npad, N, (const double*)h->Xs.p, d, ard, h->sf2, h->sn2, part1,
-                        ntheta, st);
+                        ntheta, P, rank, st);
     }
     launch_alpha_quad(h->cfg.kernel, (const double*)h->alphaT, ld, k, Npad, N, (const double*)h->Xs.p, d, ard,
                       h->sf2, h->sn2, part2, ntheta, st);
     launch_reduce_partials(part1, s1n, ntheta, 1.0, outv, st);
     launch_reduce_partials(part2, s2n, ntheta, 1.0, outv + ntheta, st);
     launch_dot_rhs((const double*)h->Y.p, (const double*)h->alphaT, ld, N, k, outv + 2 * ntheta, st);
+    if (P > 1 && (rc = cm->allreduce(h, outv, (size_t)ntheta, COMM_SUM))) return rc;
   }
   double host[2 * 34 + 1];
   HIPCHK(h, hipMemcpyAsync(host, outv, (size_t)(2 * ntheta + 1) * 8, hipMemcpyDeviceToHost, st));
@@ -1059,7 +1104,7 @@ void gpx_destroy(gpx_handle* h) {
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout, &h->G, &h->Pglob,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
-                    &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->gpart, &h->Wblk, &h->Ublk, &h->Tsol, &h->X64, &h->Y64, &h->Xs64,
+                    &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->ZTloc, &h->ZTpack, &h->gpart, &h->Wblk, &h->Ublk, &h->Tsol, &h->X64, &h->Y64, &h->Xs64,
                     &h->A64, &h->R64, &h->X32, &h->Y32, &h->RT32, &h->Q64, &h->Qs64, &h->Q32, &h->M64, &h->rn})
     release(*b);
   destroy_comm(h);
@@ -1140,9 +1185,13 @@ GPX_CATCH_ALL
 int gpx_lml_grad(gpx_handle* h, double* lml, double* grad) try {
   if (!h) return GPX_E_ARG;
   if (!h->fitted || !lml || !grad) return fail(h, GPX_E_ARG, "gpx_lml_grad: no fit or null output");
-  if (h->group || h->comm || h->cfg.world > 1)
-    return fail(h, GPX_E_UNSUPPORTED, "gpx_lml_grad: single-GPU handles only (the sharded factor is not inverted)");
   if (h->cfg.dtype != GPX_F64) return fail(h, GPX_E_UNSUPPORTED, "gpx_lml_grad: fp64 handles only");
+  if (h->group) return group_lml_grad(h, lml, grad);
+  if (h->cfg.world > 1 && !h->comm) return fail(h, GPX_E_ARG, "gpx_lml_grad: sharded handle without a communicator");
+  if (h->comm && !h->repl)
+    return fail(h, GPX_E_UNSUPPORTED,
+                "gpx_lml_grad: a sharded handle needs the replicated factor (the whole L on every rank: "
+                "N^2 within 35 % of the card, or GPX_SHARD_REPLICATE=1); the distributed-solve mode does not invert L");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->err.clear();
   h->phases.clear();
@@ -1162,7 +1211,7 @@ int gpx_release_scratch(gpx_handle* h) try {
     HIPCHK(h, hipSetDevice(m->cfg.device));
     for (hipStream_t sx : {m->st, m->st2, m->st3, m->st4})
       if (sx) HIPCHK(h, hipStreamSynchronize(sx));
-    for (DevBuf* b : {&m->ZT, &m->gpart, &m->VT, &m->Tsol, &m->Q, &m->Qs, &m->MT, &m->Sv, &m->Q64, &m->Qs64, &m->Q32,
+    for (DevBuf* b : {&m->ZT, &m->ZTloc, &m->ZTpack, &m->gpart, &m->VT, &m->Tsol, &m->Q, &m->Qs, &m->MT, &m->Sv, &m->Q64, &m->Qs64, &m->Q32,
                       &m->M64, &m->GatherS, &m->GatherR, &m->outM, &m->outV})
       release(*b);
   }

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void kinv_trace_kernel(const double* __rest
                                                             int tiles, int64_t npad, int64_t n,
                                                             const double* __restrict__ Xs, int d_rt, int ard,
                                                             double sf2, double sn2, double* __restrict__ part,
-                                                            int ntheta, int64_t nslots) {
+                                                            int ntheta, int64_t nslots, int P, int rank) {
   constexpr int BT = 128;
   __shared__ __attribute__((aligned(16))) double smem[TileShapeG<double, BT, BT>::SMEM_ELEMS];
   __shared__ double red[4];
@@ -70,8 +70,11 @@ __global__ __launch_bounds__(256, 2) void kinv_trace_kernel(const double* __rest
   // and the kernel ran at 31.6 TF.  Deal whole 64-slot groups (one super-tile: what an XCD runs
   // concurrently, so the L2 sharing inside a group is kept) round-robin over the XCDs instead:
   // neighbouring groups cost about the same, and the heavy ones still come first.
+  // Sharded call (P ranks, each holding the whole L^-T): whole octets of groups — one group per
+  // XCD — are dealt round-robin over the ranks, so every rank keeps all eight XCDs busy and its
+  // share of heavy and light tiles; rank r launches only its own octets.
   const int64_t b = blockIdx.x, xl = b >> 3;
-  const int64_t lin = (((xl >> 6) << 3) + (b & 7)) * 64 + (xl & 63);
+  const int64_t lin = ((((xl >> 6) * P + rank) << 3) + (b & 7)) * 64 + (xl & 63);
   int ti, tj;
   if (lin >= nslots || !tile_coords<true>(lin, tiles, tiles, 8, 0, BcMask{0, 1, 0}, ti, tj)) return;
   Num<double>::v4 acc[4][4];
@@ -292,16 +295,18 @@ __global__ __launch_bounds__(256) void set_diag_one_kernel(double* A, int64_t ld
 
 template <int KERNEL>
 void launch_kinv_trace_k(const double* ZT, int64_t ld, int64_t npad, int64_t n, const double* Xs, int d, int ard,
-                         double sf2, double sn2, double* part, int ntheta, hipStream_t st) {
+                         double sf2, double sn2, double* part, int ntheta, int P, int rank, hipStream_t st) {
   const int tiles = (int)(npad / 128);
   const int64_t ts = (tiles + 7) / 8;
   const int64_t nslots = ts * (ts - 1) / 2 * 64 + ts * 36;
-  dim3 grid((unsigned)((nslots + 511) / 512 * 512)), block(256);  // whole groups of 8 x 64 slots
+  const int64_t octets = (nslots + 511) / 512, mine = octets > rank ? (octets - rank + P - 1) / P : 0;
+  if (mine == 0) return;
+  dim3 grid((unsigned)(mine * 512)), block(256);  // whole octets of 8 x 64 slots
   switch (d) {
-    case 1: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 1>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots); break;
-    case 2: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 2>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots); break;
-    case 3: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 3>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots); break;
-    default: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 0>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots); break;
+    case 1: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 1>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank); break;
+    case 2: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 2>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank); break;
+    case 3: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 3>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank); break;
+    default: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 0>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank); break;
   }
 }
 
@@ -333,11 +338,11 @@ void launch_set_diag_one(double* A, int64_t lda, int64_t n, hipStream_t st) {
 }
 
 void launch_kinv_trace(int kernel, const double* ZT, int64_t ld, int64_t npad, int64_t n, const double* Xs, int d,
-                       int ard, double sf2, double sn2, double* part, int ntheta, hipStream_t st) {
+                       int ard, double sf2, double sn2, double* part, int ntheta, int P, int rank, hipStream_t st) {
   if (kernel == 0)
-    launch_kinv_trace_k<0>(ZT, ld, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, st);
+    launch_kinv_trace_k<0>(ZT, ld, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, P, rank, st);
   else
-    launch_kinv_trace_k<1>(ZT, ld, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, st);
+    launch_kinv_trace_k<1>(ZT, ld, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, P, rank, st);
 }
 
 void launch_alpha_quad(int kernel, const double* alphaT, int64_t ld, int k, int64_t npad, int64_t n,

@@ -118,9 +118,10 @@ void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st);
 int64_t kinv_trace_slots(int64_t npad);  // slots of the 128-tile triangular map
 int64_t alpha_quad_slots(int64_t npad);  // 64-tiles of the lower triangle
 void launch_set_diag_one(double* A, int64_t lda, int64_t n, hipStream_t st);
-// part[slot][t] = sum over the tile of (ZT ZT^T)_ij (dK/dlog theta_t)_ij, ZT = L^-T (npad x npad, ld)
+// part[slot][t] = sum over the tile of (ZT ZT^T)_ij (dK/dlog theta_t)_ij, ZT = L^-T (npad x npad, ld);
+// rank `rank` of P covers every P-th octet of 64-slot groups (P = 1: all of them)
 void launch_kinv_trace(int kernel, const double* ZT, int64_t ld, int64_t npad, int64_t n, const double* Xs, int d,
-                       int ard, double sf2, double sn2, double* part, int ntheta, hipStream_t st);
+                       int ard, double sf2, double sn2, double* part, int ntheta, int P, int rank, hipStream_t st);
 // part[slot][t] = sum over the tile of (sum_c alpha_ic alpha_jc) (dK/dlog theta_t)_ij, alphaT (k x npad, ld)
 void launch_alpha_quad(int kernel, const double* alphaT, int64_t ld, int k, int64_t npad, int64_t n,
                        const double* Xs, int d, int ard, double sf2, double sn2, double* part, int ntheta,

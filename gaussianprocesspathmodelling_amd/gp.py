@@ -326,7 +326,9 @@ class GP:
         gradient w.r.t. the LOG hyper-parameters, ordered (lengthscale[0..n_ls), variance, noise)
         — R&W eq. 5.9, 1/2 tr((alpha alpha^T - K^-1) dK/dtheta), computed on the GPU by
         ``gpx_lml_grad`` (about two more factorisations' worth of MFMA work: L^-T, then K^-1
-        formed and consumed tile by tile, never stored).  fp64 single-GPU models."""
+        formed and consumed tile by tile, never stored).  fp64 models; sharded ones (``devices=`` or
+        ``world=``) need the replicated-factor mode, in which L^-T is built in row blocks dealt over
+        the GPUs, all-gathered once, and the trace pass is split over the GPUs as well."""
         if not self._fitted:
             raise RuntimeError("lml_gradient() before a successful fit()")
         lml = C.c_double(0.0)
@@ -342,8 +344,9 @@ class GP:
         ``params`` chooses what moves ("lengthscale" moves every ARD entry); the search runs in
         log-space with L-BFGS-B.  ``jac="analytic"`` (default): every evaluation is one ``fit()``
         plus one ``lml_gradient()`` on the GPU, about three factorisations' worth of work whatever
-        the number of parameters.  Models without the analytic gradient (float32, sharded)
-        fall back to ``jac="3-point"`` central differences: 2 p extra fits per gradient.
+        the number of parameters.  Models without the analytic gradient (float32 / mixed, sharded
+        with distributed solves) fall back to ``jac="3-point"`` central differences: 2 p extra fits
+        per gradient.
         Non-positive-definite trial points count as very bad, they do not raise.  Leaves the
         model fitted at the best point found and returns scipy's result (``.fun`` = minus the
         log marginal likelihood there)."""
@@ -371,8 +374,17 @@ class GP:
                     i += 1
 
         best = {"f": np.inf, "v": pack()}
-        analytic = (jac == "analytic" and self.dtype == "float64" and self.world == 1
-                    and len(self.devices) <= 1 and self._host_comm is None)
+        analytic = jac == "analytic" and self.dtype == "float64"
+        if analytic and (self.world > 1 or len(self.devices) > 1 or self._host_comm is not None):
+            # sharded: the gradient needs the replicated-factor mode, which the library picks from N
+            # and the card's memory at fit time — ask it once (every rank gets the same answer)
+            try:
+                self.fit(X, y)
+                self.lml_gradient()
+            except _abi.GpxError:
+                analytic = False
+            except np.linalg.LinAlgError:
+                pass
         # columns of the full gradient (lengthscale.., variance, noise) that move
         cols = []
         for p in names:

@@ -127,7 +127,10 @@ int gpx_get_alpha(gpx_handle* h, void* out /* (N,k) host */);
  * grad[0..n_ls) = d lml / d log lengthscale, grad[n_ls] = d / d log sf2, grad[n_ls+1] = d / d log sn2
  * (n_ls as passed to gpx_fit).  Costs about two more factorisations' worth of MFMA work
  * (L^-T, then K^-1 = L^-T L^-1 consumed tile by tile as it is formed) and one extra N x N
- * buffer; K^-1 itself is never stored.  fp64, single-GPU handles. */
+ * buffer; K^-1 itself is never stored.  fp64 handles.  Sharded handles and groups: collective
+ * (every rank calls it, every rank gets the same numbers); both passes are split over the ranks
+ * with one all-gather of L^-T between them; needs the replicated-factor mode (GPX_E_UNSUPPORTED
+ * when the factor is only held distributed). */
 int gpx_lml_grad(gpx_handle* h, double* lml, double* grad);
 int gpx_logdet(gpx_handle* h, double* out);
 /* Frees what only the NEXT predict / gradient call would use (the V^T batch, the L^-T buffer of

@@ -60,6 +60,13 @@ def main():
             mean, var = gp.predict(Xs)
             res = dict(mean=mean, var=var, alpha=gp.alpha_, logdet=gp.log_det_, info=gp.info_,
                        comm_ms=gp.timings_["comm"])
+            if os.environ.get("SHARD_GRAD") == "1":
+                from gaussianprocesspathmodelling_amd import GpxError
+                try:
+                    lml, grad = gp.lml_gradient()
+                    res.update(lml=lml, grad=grad, grad_err="")
+                except GpxError as e:
+                    res.update(lml=np.nan, grad=np.zeros(0), grad_err=str(e))
     elif mode == "c4":
         if nb > 0:
             os.environ["GPX_NB_SHARD"] = str(nb)

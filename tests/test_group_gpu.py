@@ -50,6 +50,57 @@ def test_devices_surface_matches_oracle(monkeypatch, ndev, kernel, nb, N, M, rep
         assert np.array_equal(m3, mean) and np.array_equal(v3, var)
 
 
+@pytest.mark.parametrize("ndev,kernel,N,nbp,k", [
+    (2, "rbf", 1500, 256, 1), (3, "matern52", 1100, 128, 2), (4, "rbf", 3300, 256, 1),
+    (4, "rbf", 300, 256, 1),               # two blocks on four ranks: ranks 2, 3 own no row of L^-T
+    (8, "matern52", 5000, 1024, 1),        # default block height; 5 blocks on 8 ranks
+])
+def test_group_lml_gradient_matches_single_gpu_and_oracle(monkeypatch, ndev, kernel, N, nbp, k):
+    """gpx_lml_grad on a device group: row blocks of L^-T dealt over the ranks, one all-gather,
+    the K^-1 trace pass split over the ranks — against the single-GPU gradient (same kernels, other
+    summation split) and the CPU oracle's analytic gradient."""
+    monkeypatch.setenv("GPX_NB_SHARD", "128")
+    monkeypatch.setenv("GPX_NB_PRED", str(nbp))
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", "1")
+    X, y, _ = synthetic_problem(N, 3, 10, seed=31)
+    if k == 2:
+        y = np.stack([y, np.cos(3.0 * y)], axis=1)
+    ls = (0.3, 0.2, 0.25)
+    with GP(kernel, ls, 1.5, 1e-2, jitter=0.0) as g1:
+        lml1, grad1 = g1.fit(X, y).lml_gradient()
+    with GP(kernel, ls, 1.5, 1e-2, jitter=0.0, devices=ndev, oversubscribe=True) as gp:
+        lml, grad = gp.fit(X, y).lml_gradient()
+        assert abs(lml - lml1) <= 1e-10 * abs(lml1)
+        assert np.max(np.abs(grad - grad1)) <= 1e-9 * np.max(np.abs(grad1))
+        lml2, grad2 = gp.lml_gradient()            # again on the same fit: buffers reused
+        assert lml2 == lml and np.array_equal(grad2, grad)
+        tm = gp.timings_
+        assert tm["grad_total"] > 0 and tm["grad_trace"] > 0
+    if k == 1:
+        ref = OracleGP(kernel, ls, 1.5, 1e-2, jitter=0.0).fit(X, y)
+        lml_o, grad_o = ref.log_marginal_likelihood(), ref.lml_gradient()
+        assert abs(lml - lml_o) <= 1e-9 * abs(lml_o)
+        assert np.max(np.abs(grad - grad_o)) <= 1e-7 * np.max(np.abs(grad_o))
+
+
+def test_group_gradient_needs_replicated_factor_and_optimize_falls_back(monkeypatch):
+    monkeypatch.setenv("GPX_NB_SHARD", "128")
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", "0")
+    X, y, _ = synthetic_problem(500, 2, 10, seed=3)
+    with GP("rbf", 0.5, 1.0, 0.1, devices=2, oversubscribe=True) as gp:
+        gp.fit(X, y)
+        with pytest.raises(GpxError, match="replicated factor"):
+            gp.lml_gradient()
+        res = gp.optimize(X, y, maxiter=3)          # central differences instead
+        assert np.isfinite(res.fun)
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", "1")
+    with GP("rbf", 0.5, 1.0, 0.1, devices=2, oversubscribe=True) as gp, GP("rbf", 0.5, 1.0, 0.1) as g1:
+        r2 = gp.optimize(X, y, maxiter=25)          # analytic gradient on the group
+        r1 = g1.optimize(X, y, maxiter=25)
+        assert abs(r2.fun - r1.fun) <= 1e-6 * abs(r1.fun)
+        assert np.allclose(gp.lengthscale, g1.lengthscale, rtol=1e-3) and np.isclose(gp.noise, g1.noise, rtol=1e-3)
+
+
 @pytest.mark.parametrize("repl", [0, 1])
 def test_group_predict_in_batches(monkeypatch, repl):
     """Sharded predict with GPX_PRED_BATCH = 128: several batches, each with its own look-ahead

@@ -42,6 +42,19 @@ def test_sharded_schedule_single_rank_rccl(N, M, nb, repl, monkeypatch):
         assert np.max(np.abs(gp.predict(Xs, return_var=False) - mean)) <= 1e-9 * max(1.0, np.abs(mean).max())
 
 
+def test_single_rank_rccl_lml_gradient(monkeypatch):
+    """The sharded gradient path with P = 1 over a real RCCL communicator (broadcast-free, the
+    all-reduce skipped): the plain single-GPU handle's numbers (the factor comes from the sharded
+    schedule, so agreement is to rounding, not bitwise)."""
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", "1")
+    X, y, _ = synthetic_problem(2000, 3, 10, seed=4)
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0) as g1:
+        lml1, grad1 = g1.fit(X, y).lml_gradient()
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0, device=0, world=1, rank=0, comm="rccl") as gp:
+        lml, grad = gp.fit(X, y).lml_gradient()
+    assert abs(lml - lml1) <= 1e-10 * abs(lml1) and np.max(np.abs(grad - grad1)) <= 1e-9 * np.max(np.abs(grad1))
+
+
 @pytest.mark.parametrize("world,kernel,nb,N,repl", [
     (2, "rbf", 128, 700, 0), (3, "matern52", 128, 700, 0), (2, "rbf", 256, 700, 0), (4, "rbf", 512, 3300, 0),
     (2, "rbf", 128, 700, 1), (3, "matern52", 128, 700, 1), (4, "rbf", 512, 3300, 1),
@@ -64,6 +77,27 @@ def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N, repl):
         check(r["mean"], r["var"], r["alpha"], float(r["logdet"]), ref, mr, vr)
     # every rank returns the same replicated result
     assert np.array_equal(res[0]["mean"], res[-1]["mean"]) and np.array_equal(res[0]["var"], res[-1]["var"])
+
+
+@pytest.mark.parametrize("world,N,nbp", [(2, 1500, 256), (3, 1100, 128)])
+def test_sharded_lml_gradient_over_host_transport(tmp_path, world, N, nbp):
+    """gpx_lml_grad on a row-block shard (one process per rank, host transport): L^-T in row blocks
+    dealt over the ranks, all-gather, trace pass split over the ranks — against the CPU oracle's
+    analytic gradient; identical on every rank.  The distributed-solve mode refuses."""
+    env = {"SHARD_KERNEL": "matern52", "SHARD_NB": "128", "SHARD_N": str(N), "SHARD_GRAD": "1",
+           "GPX_NB_PRED": str(nbp), "GPX_SHARD_REPLICATE": "1"}
+    res = run_ranks("gpu", world, tmp_path, env, timeout=600)
+    X, y, _ = synthetic_problem(N, 3, 90, seed=77)
+    ref = OracleGP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
+    lml_o, grad_o = ref.log_marginal_likelihood(), ref.lml_gradient()
+    for r in res:
+        assert str(r["grad_err"]) == ""
+        assert abs(float(r["lml"]) - lml_o) <= 1e-9 * abs(lml_o)
+        assert np.max(np.abs(r["grad"] - grad_o)) <= 1e-7 * np.max(np.abs(grad_o))
+        assert np.array_equal(r["grad"], res[0]["grad"])
+    env["GPX_SHARD_REPLICATE"] = "0"
+    res = run_ranks("gpu", world, tmp_path, env, timeout=600)
+    assert all("replicated factor" in str(r["grad_err"]) for r in res)
 
 
 def test_c4_shape_on_one_gpu_world4(tmp_path):
