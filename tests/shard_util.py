@@ -15,24 +15,42 @@ def free_port():
 
 
 def run_ranks(mode, world, tmp_path, env_extra=None, timeout=300):
-    """Launch `world` worker processes on 127.0.0.1 and return their result dicts."""
+    """Launch `world` worker processes on 127.0.0.1 and return their result dicts.  Worker output
+    goes to files (a full pipe would block a rank inside a collective); a rank that dies takes the
+    others down at once instead of leaving them waiting for it in a collective until the timeout."""
+    import time
     port = free_port()
     out = os.path.join(str(tmp_path), f"{mode}_w{world}")
-    procs = []
+    procs, logf = [], []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="2", **(env_extra or {}))
+        logf.append(open(out + f".rank{rank}.log", "wb"))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), mode, out],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = []
+                                      env=env, stdout=logf[-1], stderr=subprocess.STDOUT))
+    deadline = time.monotonic() + timeout
+    why = ""
     try:
-        for p in procs:
-            o, _ = p.communicate(timeout=timeout)
-            logs.append(o.decode(errors="replace"))
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            if any(c not in (None, 0) for c in codes):
+                why = "a rank failed; the others were stopped"
+                break
+            if time.monotonic() > deadline:
+                why = f"timeout after {timeout} s"
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:          # exact PIDs we started, never a pattern
             if p.poll() is None:
                 p.kill()
+                p.wait()
+        for f in logf:
+            f.close()
+    logs = [open(out + f".rank{r}.log", "rb").read().decode(errors="replace") for r in range(world)]
     for rank, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {rank} failed:\n{logs[rank][-3000:]}"
+        assert p.returncode == 0 and not why, (f"rank {rank} exit code {p.returncode} ({why})\n" +
+                                               "\n".join(f"--- rank {r} ---\n{logs[r][-3000:]}" for r in range(world)))
     return [dict(np.load(out + f".rank{r}.npz", allow_pickle=False)) for r in range(world)]
