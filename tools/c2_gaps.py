@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Gap analysis of the diagonal chain from a rocprofv3 kernel trace of tools/c2_bench.py
+(tools/c2_trace.sh): for the LAST fit in the trace, the chain kernels in start order —
+potf2_64 -> in-block solve -> in-block SYRK — with their durations and the idle time between the
+end of one and the start of the next.   python tools/c2_gaps.py gpurun_out/c2trace/trace.csv"""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows:
+    r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+rows.sort(key=lambda r: r["s"])
+short = lambda n: ("potf2" if "potf2" in n else "trsm" if "trsm_rlt" in n else "syrk64" if "gemm_nt_kernel<double, 64, true" in n
+                   else "gemm128" if "gemm_nt_kernel<double, 128" in n else "ltri" if "ltri" in n else "gemm64" if "gemm_nt_kernel<double, 64" in n
+                   else "kbuild" if "kbuild" in n else "copy" if "copy" in n.lower() else "fill" if "fill" in n else n[:24])
+# last fit = after the last symmetric kbuild
+ks = [i for i, r in enumerate(rows) if "kbuild_kernel<double, 0, true" in r["Kernel_Name"]]
+fit = rows[ks[-1]:]
+pot = [i for i, r in enumerate(fit) if "potf2" in r["Kernel_Name"]]
+print("kernels in last fit+predict:", len(fit), " potf2 launches:", len(pot))
+# per 64-step: potf2 start to next potf2 start, within the first diagonal block (16 steps)
+def seg(a, b):
+    out = []
+    for r in fit[a:b]:
+        out.append(f'{short(r["Kernel_Name"])}[q{r["Queue_Id"]}] {(r["s"]-fit[a]["s"])/1e3:7.1f}+{(r["e"]-r["s"])/1e3:5.1f}')
+    return out
+for blk in (0, 3):
+    print(f"--- diagonal block {blk}, steps 2..5 (us from the step's potf2 start: start+duration) ---")
+    for st in range(2, 6):
+        a, b = pot[blk * 16 + st], pot[blk * 16 + st + 1]
+        print(f"step {st}: {(fit[b]['s'] - fit[a]['s'])/1e3:6.1f} us |", "  ".join(seg(a, b)))
+tot = collections.Counter(); cnt = collections.Counter()
+for i in range(len(pot) - 1):
+    if (i + 1) % 16 == 0: continue
+    tot["step"] += fit[pot[i + 1]]["s"] - fit[pot[i]]["s"]; cnt["step"] += 1
+    tot["potf2"] += fit[pot[i]]["e"] - fit[pot[i]]["s"]
+print("mean step (potf2 start to next potf2 start, inside a block): %.1f us; potf2 itself %.1f us" % (tot["step"] / cnt["step"] / 1e3, tot["potf2"] / cnt["step"] / 1e3))
