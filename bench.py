@@ -182,7 +182,9 @@ def main():
     ap.add_argument("--ntrain", dest="n", type=int, default=N_TRAIN, help="override N (debug only; invalidates the metric)")
     ap.add_argument("--mtest", dest="m", type=int, default=M_TEST)
     ap.add_argument("--block", type=int, default=0)
-    ap.add_argument("--mode", choices=["auto", "replicas", "shard"], default="auto")
+    ap.add_argument("--mode", choices=["auto", "replicas", "shard", "group"], default="auto",
+                    help="auto: N > 1 runs 'shard' (one process per GPU over RCCL) supervised, and if that fails 'group' "
+                         "(rank 0 drives all N GPUs as one in-process device group over peer copies: same schedule, no RCCL)")
     ap.add_argument("--heartbeat", default=None, help="(internal) progress file of a supervised sharded child")
     ap.add_argument("--stall-timeout", type=float, default=300.0,
                     help="auto mode: seconds without child progress before the run counts as failed")
@@ -198,11 +200,24 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if args.mode == "auto":
         if world > 1:
-            failure = supervise_sharded_child(args)
+            failure = supervise_sharded_child(args, "shard")
             if failure is None:
                 return                      # the child printed the JSON line
-            # The graded multi-GPU path failed.  Say so and stop: no replicas number takes the
-            # place of `value`, and the exit code is non-zero on every rank.
+            # The RCCL transport failed.  The SAME sharded schedule has a second transport that needs
+            # no RCCL and no inter-process IPC: rank 0 drives all GPUs as one in-process device group
+            # (peer copies + hipEvents).  It is tried once, labelled as such in the JSON line, with
+            # the reason the first attempt failed.
+            os.environ["GPX_BENCH_FALLBACK_REASON"] = failure[:500]
+            # a fresh rendezvous for the second attempt: the launcher's agent store still holds the
+            # first attempt's keys, so the children host their own store on the next port
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+            failure2 = supervise_sharded_child(args, "group")
+            if failure2 is None:
+                return
+            failure = f"shard over RCCL: {failure}; in-process device group: {failure2}"
+            # Both transports of the graded multi-GPU path failed.  Say so and stop: no replicas
+            # number takes the place of `value`, and the exit code is non-zero on every rank.
             if int(os.environ.get("RANK", "0")) == 0:
                 print(json.dumps({
                     "metric": "gp_fit_predict_points_per_sec", "value": None, "unit": "points/s",
@@ -224,8 +239,8 @@ def beat(args, what):
             f.write(f"{time.time():.3f} {what}\n")
 
 
-def supervise_sharded_child(args):
-    """Run ``--mode shard`` in a child process (exact PID kept), watch its heartbeat file and
+def supervise_sharded_child(args, mode):
+    """Run ``--mode shard`` (or ``group``) in a child process (exact PID kept), watch its heartbeat file and
     the node-wide failure flag.  Returns None when the child finished ("done" mark), else the
     reason it failed.  Nothing here touches the GPU."""
     import subprocess
@@ -240,13 +255,13 @@ def supervise_sharded_child(args):
             born = f.read().rsplit(")", 1)[1].split()[19]
     except Exception:
         born = "0"
-    tag = f"gpx_bench_{os.environ.get('MASTER_PORT', '0')}_{ppid}_{born}"
+    tag = f"gpx_bench_{mode}_{os.environ.get('MASTER_PORT', '0')}_{ppid}_{born}"
     tmp = tempfile.gettempdir()
     hb = os.path.join(tmp, f"{tag}_hb{rank}")
     flag = os.path.join(tmp, f"{tag}_failed")
     open(hb, "w").close()
     argv = [a for a in sys.argv[1:]]
-    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--mode", "shard", "--heartbeat", hb]
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--mode", mode, "--heartbeat", hb]
     child = subprocess.Popen(cmd)
     reason = None
     last = ""
@@ -267,13 +282,13 @@ def supervise_sharded_child(args):
                     child.kill()
             return None
         if rc is not None:
-            reason = f"sharded child of rank {rank} exited with code {rc} after '{last}'"
+            reason = f"{mode} child of rank {rank} exited with code {rc} after '{last}'"
             break
         if os.path.exists(flag):
-            reason = "sharded child of another rank failed"
+            reason = f"{mode} child of another rank failed"
             break
         if age > args.stall_timeout:
-            reason = f"sharded child of rank {rank} made no progress for {age:.0f} s after '{last}'"
+            reason = f"{mode} child of rank {rank} made no progress for {age:.0f} s after '{last}'"
             break
         time.sleep(0.5)
     try:
@@ -284,7 +299,7 @@ def supervise_sharded_child(args):
     if child.poll() is None:
         child.kill()                        # exact PID of the process started above
         child.wait()
-    print(f"[bench] sharded run FAILED: {reason}", file=sys.stderr, flush=True)
+    print(f"[bench] {mode} run FAILED: {reason}", file=sys.stderr, flush=True)
     time.sleep(3.0)                         # let the other ranks see the flag and reap their children
     try:
         with open(flag) as f:
@@ -312,7 +327,7 @@ def run(args):
     # Sharded runs: torch.distributed is only the control plane (RCCL unique id, barriers, the
     # max-over-ranks time) and runs on gloo; the data path is libgpx.so calling RCCL itself.
     # Replicas have no data path between ranks: their barriers go over torch's RCCL backend.
-    ctrl_nccl = args.backend == "nccl" and args.mode != "shard"
+    ctrl_nccl = args.backend == "nccl" and args.mode not in ("shard", "group")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if ctrl_nccl:
@@ -329,12 +344,19 @@ def run(args):
         if args.n == N_TRAIN:
             N = 262144
         kernel = "matern52"
-        if not (args.mode == "shard" and world >= 2):
+        if not (args.mode in ("shard", "group") and world >= 2):
             raise SystemExit("--workload C4 (550 GB Gram matrix) needs --mode shard on several GPUs")
-    shard = args.mode == "shard"     # world == 1: the sharded schedule on one rank (its own overhead)
+    group = args.mode == "group"     # rank 0 drives all `world` GPUs from this one process; the other ranks only keep time
+    shard = args.mode == "shard" or group   # world == 1: the sharded schedule on one rank (its own overhead)
     X, y, Xs = synthetic(N, DIM, M, 12345 + (0 if shard else rank))   # replicas: own draw each
     Xd, yd, Xsd = (torch.from_numpy(a).to(dev) for a in (X, y, Xs))
-    if shard:
+    if group:
+        gp = None
+        if rank == 0:
+            devs = [args.device] * world if args.device is not None else list(range(world))
+            gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, block=args.block, profile=True, devices=devs,
+                    transport="local", oversubscribe=args.device is not None)
+    elif shard:
         gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True,
                 world=world, rank=rank, comm="rccl" if args.backend == "nccl" else "host")
     else:
@@ -352,9 +374,14 @@ def run(args):
             torch.cuda.synchronize(dev)
 
     def step():
+        if gp is None:                      # group mode, rank > 0: rank 0's process holds every GPU
+            beat(args, "step")
+            return None, None, {}
         gp.fit(Xd, yd)
         mean, var = gp.predict(Xsd)
         beat(args, "step")
+        if group:
+            return mean, var, gp.timings_
         if shard and inject == f"fail:{rank}":
             raise RuntimeError("injected failure (GPX_BENCH_INJECT)")
         if shard and inject == f"hang:{rank}":
@@ -376,7 +403,7 @@ def run(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if ctrl_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ok = bool(torch.isfinite(mean).all().item() and (var > 0).all().item())
+    ok = True if gp is None else bool(torch.isfinite(mean).all().item() and (var > 0).all().item())
     pcie_ms = None
     if world == 1 and not shard:
         # the same step with HOST NumPy arrays in and out (H2D of X, y, Xs and D2H of mean, var inside
@@ -432,10 +459,12 @@ def run(args):
                                    f"M={M}, inputs resident in HBM", "N": N, "d": DIM, "M": M,
                        "kernel": kernel, "block": args.block or (shard_block(N, world) if shard else 1024),
                        "parallelism": "1 gpu" if world == 1 else
-                       (f"row-block-cyclic shard over {world} gpus ({'RCCL' if args.backend == 'nccl' else 'host collectives, rehearsal'})" if shard
+                       (f"row-block-cyclic shard over {world} gpus (one process, in-process peer-copy transport)" if group else
+                        f"row-block-cyclic shard over {world} gpus ({'RCCL' if args.backend == 'nccl' else 'host collectives, rehearsal'})" if shard
                         else f"{world} independent replicas")},
             "outputs_finite": ok,
             "shard_check": shard_check,
+            **({"fallback_from": os.environ["GPX_BENCH_FALLBACK_REASON"]} if group and os.environ.get("GPX_BENCH_FALLBACK_REASON") else {}),
             "phases_ms": phases,
             "roofline": {
                 "kernel": "gemm_nt_kernel<128,LOWER> (trailing SYRK of the blocked Cholesky)",
@@ -469,7 +498,8 @@ def run(args):
     elif world > 1:
         sync()
     beat(args, "done")
-    gp.close()
+    if gp is not None:
+        gp.close()
     if world > 1:
         dist.destroy_process_group()
 
