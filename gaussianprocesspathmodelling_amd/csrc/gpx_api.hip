@@ -99,6 +99,7 @@ struct gpx_handle {
   DevBuf X64, Y64, Xs64, A64, R64, X32, Y32, RT32, Q64, Qs64, Q32, M64, rn;
   int refine = 3;
   DevBuf Tsol;       // predict: compact solved blocks of V^T (2 x batch x (nb + skew))
+  DevBuf MTpart;         // split-K partial tiles of the posterior-mean product
   DevBuf ZTloc, ZTpack;  // sharded gradient: own row blocks of L^-T (stacked), one packed block in flight
   DevBuf Wblk, Ublk; // explicit inverses of the nb x nb diagonal blocks of L ([Npad/nb][nb][nb]) + scratch
   int nbw = 0;       // block width of Wblk (0: not built)
@@ -668,6 +669,9 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
   if ((rc = ensure(h, h->Qs, (size_t)Mpad * d * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->VT, (size_t)MB * ld * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->MT, (size_t)RHS_ROWS * ldm * sizeof(T)))) return rc;
+  // the mean is a 64-row product with K = N: split the contraction so that it fills the chip
+  const int ksplit = splitk_splits(Npad);
+  if (ksplit > 1 && (rc = ensure(h, h->MTpart, (size_t)ksplit * RHS_ROWS * ldm * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->meanout, (size_t)M * k * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->var, (size_t)Mpad * sizeof(T)))) return rc;
   SolveWork<T> sw;
@@ -705,7 +709,11 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
     {  // with the variance: mean^T (64 x mp) = z^T (64 x Npad) * V   (mu = K* K^-1 y = V^T z);
        // mean only: alpha^T * K*^T
       PhaseScope ps(h, &tm.mean);
-      launch_gemm_nt<T>(64, (T*)h->MT.p + m0, ldm, rhsT, ld, dVT, ld, RHS_ROWS, mp, Npad, 0, 1, h->st);
+      if (ksplit > 1)
+        launch_gemm_nt_splitk<T>((T*)h->MT.p + m0, ldm, rhsT, ld, dVT, ld, RHS_ROWS, mp, Npad, ksplit,
+                                 (T*)h->MTpart.p + m0, (int64_t)RHS_ROWS * ldm, h->st);
+      else
+        launch_gemm_nt<T>(64, (T*)h->MT.p + m0, ldm, rhsT, ld, dVT, ld, RHS_ROWS, mp, Npad, 0, 1, h->st);
     }
     if (want_var) {
       PhaseScope ps(h, &tm.var);
@@ -1102,7 +1110,7 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st3) (void)hipStreamSynchronize(h->st3);
   if (h->st4) (void)hipStreamSynchronize(h->st4);
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
-                    &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->var, &h->meanout, &h->G, &h->Pglob,
+                    &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->MTpart, &h->var, &h->meanout, &h->G, &h->Pglob,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
                     &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->ZTloc, &h->ZTpack, &h->gpart, &h->Wblk, &h->Ublk, &h->Tsol, &h->X64, &h->Y64, &h->Xs64,
                     &h->A64, &h->R64, &h->X32, &h->Y32, &h->RT32, &h->Q64, &h->Qs64, &h->Q32, &h->M64, &h->rn})
@@ -1211,7 +1219,7 @@ int gpx_release_scratch(gpx_handle* h) try {
     HIPCHK(h, hipSetDevice(m->cfg.device));
     for (hipStream_t sx : {m->st, m->st2, m->st3, m->st4})
       if (sx) HIPCHK(h, hipStreamSynchronize(sx));
-    for (DevBuf* b : {&m->ZT, &m->ZTloc, &m->ZTpack, &m->gpart, &m->VT, &m->Tsol, &m->Q, &m->Qs, &m->MT, &m->Sv, &m->Q64, &m->Qs64, &m->Q32,
+    for (DevBuf* b : {&m->ZT, &m->ZTloc, &m->ZTpack, &m->gpart, &m->MTpart, &m->VT, &m->Tsol, &m->Q, &m->Qs, &m->MT, &m->Sv, &m->Q64, &m->Qs64, &m->Q32,
                       &m->M64, &m->GatherS, &m->GatherR, &m->outM, &m->outV})
       release(*b);
   }

@@ -296,6 +296,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stair_kernel(
   store_tile<T, BT, BT, MODE>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
 }
 
+// ---- skinny products with a long contraction: split-K into partial tiles ---------------------
+// C (m x n) = A (m x K) B(n x K)^T with m = 64 and K = N (the posterior mean: z^T V or alpha^T K*^T)
+// has n / 64 tiles, each walking the whole K — 64 workgroups on 256 CUs for a 3.4 ms latency chain
+// at N = 65536.  blockIdx.y = split s contracts k in [s Ks, min(K, (s+1) Ks)) into
+// part[s] (m x ldc); splitk_reduce_kernel adds the S partial tiles in split order, so the result
+// is deterministic (no atomics).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(T* __restrict__ part, int64_t ldc, int64_t pstride,
+                                                               const T* __restrict__ A, int64_t lda,
+                                                               const T* __restrict__ B, int64_t ldb, int tiles_n,
+                                                               int K, int Ks) {
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 64, 64>::SMEM_ELEMS];
+  const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n, sidx = blockIdx.y;
+  const int k0 = sidx * Ks, kn = min(Ks, K - k0);
+  typename Num<T>::v4 acc[2][2];
+  zero_acc(acc);
+  gemm_tile_g<T, 64, 64>(A + (int64_t)ti * 64 * lda + k0, lda, B + (int64_t)tj * 64 * ldb + k0, ldb, kn, acc, smem);
+  store_tile<T, 64, 64, 1>(part + sidx * pstride + (int64_t)ti * 64 * ldc + (int64_t)tj * 64, ldc, acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ part,
+                                                           int64_t pstride, int S, int64_t m, int64_t n) {
+  const int64_t r = blockIdx.y;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.x * 256) {
+    T v = part[r * ldc + c];
+    for (int q = 1; q < S; ++q) v += part[q * pstride + r * ldc + c];
+    C[r * ldc + c] = v;
+  }
+  (void)m;
+}
+
 // ---- experimental 256x128 tile, 8 waves (4 x 2, each 64x64): one workgroup per CU ------------
 // Lower triangle of C (m == n, multiples of 256) -= A A^T-style NT product.  Tile row ti (256
 // rows) owns tile columns tj <= 2 ti + 1 (128 wide): the staircase map with P = 2, tpb = 1,
@@ -745,6 +777,24 @@ void launch_trsm_rln(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
                      Winv, nb / 64);
 }
 
+// splits for a skinny product (see gemm_nt_splitk_kernel): a function of the contraction length
+// ONLY — the summation order of an output element must not depend on how many columns happen to be
+// computed beside it (predicting query points in batches is bit-identical to one pass) — splits of
+// at least 1024, at most 16 of them (N = 65536, M = 4096: 64 tiles x 16 = 1024 workgroups)
+int splitk_splits(int64_t k) { return (int)std::max<int64_t>(1, std::min<int64_t>(16, k / 1024)); }
+
+template <typename T>
+void launch_gemm_nt_splitk(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
+                           int64_t n, int64_t k, int S, T* part, int64_t pstride, hipStream_t st) {
+  const int64_t Ks = ((k + S - 1) / S + 127) / 128 * 128;
+  const int Sx = (int)((k + Ks - 1) / Ks);  // splits that are not empty
+  hipLaunchKernelGGL(gemm_nt_splitk_kernel<T>, dim3((unsigned)((m / 64) * (n / 64)), (unsigned)Sx), dim3(256), 0, st, part,
+                     ldc, pstride, A, lda, B, ldb, (int)(n / 64), (int)k, (int)Ks);
+  const int64_t bx = (n + 255) / 256;
+  hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)std::min<int64_t>(bx, 64), (unsigned)m), dim3(256), 0, st, C,
+                     ldc, part, pstride, Sx, m, n);
+}
+
 template <typename T>
 void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                     int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st) {
@@ -854,7 +904,9 @@ extern "C" int gpx_debug_read_syrk_clock(long long* out) {
   template void launch_gemm_nt_bc<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,        \
                                      int64_t, int64_t, int, int, int, hipStream_t);                     \
   template void launch_gemm_nn<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t, int64_t,  \
-                                  int64_t, hipStream_t);
+                                  int64_t, hipStream_t);                                                \
+  template void launch_gemm_nt_splitk<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,    \
+                                         int64_t, int64_t, int, T*, int64_t, hipStream_t);
 GPX_INSTANTIATE_BLAS(double)
 GPX_INSTANTIATE_BLAS(float)
 
