@@ -671,7 +671,8 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
   if ((rc = ensure(h, h->MT, (size_t)RHS_ROWS * ldm * sizeof(T)))) return rc;
   // the mean is a 64-row product with K = N: split the contraction so that it fills the chip
   const int ksplit = splitk_splits(Npad);
-  if (ksplit > 1 && (rc = ensure(h, h->MTpart, (size_t)ksplit * RHS_ROWS * ldm * sizeof(T)))) return rc;
+  const int64_t ldpm = std::min(MB, Mpad) + ld_skew<T>();  // partial tiles of ONE batch
+  if (ksplit > 1 && (rc = ensure(h, h->MTpart, (size_t)ksplit * RHS_ROWS * ldpm * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->meanout, (size_t)M * k * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->var, (size_t)Mpad * sizeof(T)))) return rc;
   SolveWork<T> sw;
@@ -711,7 +712,7 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
       PhaseScope ps(h, &tm.mean);
       if (ksplit > 1)
         launch_gemm_nt_splitk<T>((T*)h->MT.p + m0, ldm, rhsT, ld, dVT, ld, RHS_ROWS, mp, Npad, ksplit,
-                                 (T*)h->MTpart.p + m0, (int64_t)RHS_ROWS * ldm, h->st);
+                                 (T*)h->MTpart.p, ldpm, h->st);
       else
         launch_gemm_nt<T>(64, (T*)h->MT.p + m0, ldm, rhsT, ld, dVT, ld, RHS_ROWS, mp, Npad, 0, 1, h->st);
     }

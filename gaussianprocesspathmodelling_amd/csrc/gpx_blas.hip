@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stair_kernel(
 // part[s] (m x ldc); splitk_reduce_kernel adds the S partial tiles in split order, so the result
 // is deterministic (no atomics).
 template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(T* __restrict__ part, int64_t ldc, int64_t pstride,
+__global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(T* __restrict__ part, int64_t ldp, int64_t pstride,
                                                                const T* __restrict__ A, int64_t lda,
                                                                const T* __restrict__ B, int64_t ldb, int tiles_n,
                                                                int K, int Ks) {
@@ -313,19 +313,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(T* __restrict__ 
   typename Num<T>::v4 acc[2][2];
   zero_acc(acc);
   gemm_tile_g<T, 64, 64>(A + (int64_t)ti * 64 * lda + k0, lda, B + (int64_t)tj * 64 * ldb + k0, ldb, kn, acc, smem);
-  store_tile<T, 64, 64, 1>(part + sidx * pstride + (int64_t)ti * 64 * ldc + (int64_t)tj * 64, ldc, acc);
+  store_tile<T, 64, 64, 1>(part + sidx * pstride + (int64_t)ti * 64 * ldp + (int64_t)tj * 64, ldp, acc);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ part,
-                                                           int64_t pstride, int S, int64_t m, int64_t n) {
+                                                           int64_t ldp, int64_t pstride, int S, int64_t n) {
   const int64_t r = blockIdx.y;
   for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.x * 256) {
-    T v = part[r * ldc + c];
-    for (int q = 1; q < S; ++q) v += part[q * pstride + r * ldc + c];
+    T v = part[r * ldp + c];
+    for (int q = 1; q < S; ++q) v += part[q * pstride + r * ldp + c];
     C[r * ldc + c] = v;
   }
-  (void)m;
 }
 
 // ---- experimental 256x128 tile, 8 waves (4 x 2, each 64x64): one workgroup per CU ------------
@@ -785,14 +784,15 @@ int splitk_splits(int64_t k) { return (int)std::max<int64_t>(1, std::min<int64_t
 
 template <typename T>
 void launch_gemm_nt_splitk(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
-                           int64_t n, int64_t k, int S, T* part, int64_t pstride, hipStream_t st) {
+                           int64_t n, int64_t k, int S, T* part, int64_t ldp, hipStream_t st) {
   const int64_t Ks = ((k + S - 1) / S + 127) / 128 * 128;
   const int Sx = (int)((k + Ks - 1) / Ks);  // splits that are not empty
+  const int64_t pstride = m * ldp;          // part: [S][m][ldp]
   hipLaunchKernelGGL(gemm_nt_splitk_kernel<T>, dim3((unsigned)((m / 64) * (n / 64)), (unsigned)Sx), dim3(256), 0, st, part,
-                     ldc, pstride, A, lda, B, ldb, (int)(n / 64), (int)k, (int)Ks);
+                     ldp, pstride, A, lda, B, ldb, (int)(n / 64), (int)k, (int)Ks);
   const int64_t bx = (n + 255) / 256;
   hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3((unsigned)std::min<int64_t>(bx, 64), (unsigned)m), dim3(256), 0, st, C,
-                     ldc, part, pstride, Sx, m, n);
+                     ldc, part, ldp, pstride, Sx, n);
 }
 
 template <typename T>

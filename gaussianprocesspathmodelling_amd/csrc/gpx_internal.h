@@ -77,11 +77,11 @@ void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const 
 // Sharded trailing update: C (m local rows x n, 128-tiles) -= A B^T restricted to tiles with
 //   tile_col <= ((tile_row / tpb) * P + c) * tpb + tile_row % tpb   (block-cyclic rows).
 // C (m x n) = A (m x k) B(n x k)^T for skinny C with a long contraction (m, n multiples of 64): S
-// splits of k into partial tiles part[s] (m x ldc each, pstride apart), summed in split order
+// splits of k into partial tiles part[s] (m x ldp each, back to back), summed in split order
 int splitk_splits(int64_t k);  // depends on k only: batching the columns must not change the bits
 template <typename T>
 void launch_gemm_nt_splitk(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
-                           int64_t n, int64_t k, int S, T* part, int64_t pstride, hipStream_t st);
+                           int64_t n, int64_t k, int S, T* part, int64_t ldp, hipStream_t st);
 template <typename T>
 void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
                        int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c, hipStream_t st);

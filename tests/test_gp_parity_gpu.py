@@ -241,13 +241,14 @@ def test_config_C3_n65536_properties():
         print("C3 timings:", gp.timings_)
         # M = 65536 query points at N = 65536: K* / V^T would be 34 GB in one piece; predict
         # streams them in batches of 8192 rows through one 4.3 GB buffer.  Stated budget for
-        # the whole handle: factor 34.4 GB + panels 1.1 GB + V^T batch 4.3 GB + block inverses, compact blocks, runtime context < 44 GB.
+        # the whole handle: factor 34.4 GB + panels 1.1 GB + V^T batch 4.3 GB + block inverses 0.5 GB + compact
+        # blocks and split-K partial tiles of one batch 0.2 GB + runtime context < 44.5 GB (one piece: 34 GB more).
         import torch
         Xbig = np.random.default_rng(2).uniform(0, 1, (65536, d))
         Xbig[:M] = Xs
         mb, vb = gp.predict(Xbig)
         free, total = torch.cuda.mem_get_info(0)
-        assert total - free <= 44e9, f"{(total - free) / 1e9:.1f} GB in use"
+        assert total - free <= 44.5e9, f"{(total - free) / 1e9:.1f} GB in use"
         assert np.array_equal(mb[:M], mean) and np.array_equal(vb[:M], var)   # same rows, batched or not
         assert np.all(np.isfinite(mb)) and np.all(vb > 0) and np.all(vb < sf2)
         print("M=65536 predict:", {k_: round(v_, 1) for k_, v_ in gp.timings_.items() if k_ in ("kstar", "trsm", "mean", "var", "predict_total")})
