@@ -81,6 +81,7 @@ SIGNATURES = {
     "gpx_debug_tile_map": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]),
     "gpx_debug_local_hub": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "gpx_debug_set_delay": (C.c_int, [C.c_uint64]),
     "gpx_debug_gemm_bench": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                        C.POINTER(C.c_double)]),
     "gpx_mfma_probe": (C.c_int, [_PD, _PD, _PD]),

@@ -1556,6 +1556,11 @@ int gpx_debug_gemm_bench(int32_t dtype, int64_t n, int64_t k, int32_t lower, int
 }
 GPX_CATCH_ALL
 
+int gpx_debug_set_delay(uint64_t seed) {
+  debug_set_delay(seed);
+  return GPX_OK;
+}
+
 int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t tpb, int32_t c, int32_t* out,
                        int64_t cap, int64_t* count) try {
   if (!out || !count || tm <= 0 || cap <= 0 || (kind != 0 && kind != 1)) return GPX_E_ARG;

@@ -741,12 +741,14 @@ int take_launch_error() { return g_launch_error.exchange(0); }
 
 template <typename T>
 void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st) {
+  debug_delay(st);
   hipLaunchKernelGGL(potf2_64_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, Winv, gidx0, info);
 }
 
 template <typename T>
 void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, const T* Winv, int nb,
                      T* P, int64_t ldp, hipStream_t st) {
+  debug_delay(st);
   // the kernel's L1 invariant (see trsm_rlt_kernel): 128-byte aligned rows of X.  Every caller
   // builds ldx from ld_skew<T>(); a violation is a programming error in this library, caught
   // here before a silently stale read can happen.
@@ -761,6 +763,7 @@ void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
 template <typename T>
 void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv, int q0, int q1, T* W,
                        int64_t ldw, hipStream_t st) {
+  debug_delay(st);
   if (((uintptr_t)U | (uintptr_t)(ldu * (int64_t)sizeof(T))) % 128 != 0) {
     g_launch_error.store(1);
     return;
@@ -772,6 +775,7 @@ void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv
 template <typename T>
 void launch_trsm_rln(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, const T* Winv, int nb,
                      hipStream_t st) {
+  debug_delay(st);
   hipLaunchKernelGGL(trsm_rln_kernel<T>, dim3((unsigned)(rows / 64)), dim3(256), 0, st, X, ldx, L, ldl,
                      Winv, nb / 64);
 }
@@ -785,6 +789,7 @@ int splitk_splits(int64_t k) { return (int)std::max<int64_t>(1, std::min<int64_t
 template <typename T>
 void launch_gemm_nt_splitk(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
                            int64_t n, int64_t k, int S, T* part, int64_t ldp, hipStream_t st) {
+  debug_delay(st);
   const int64_t Ks = ((k + S - 1) / S + 127) / 128 * 128;
   const int Sx = (int)((k + Ks - 1) / Ks);  // splits that are not empty
   const int64_t pstride = m * ldp;          // part: [S][m][ldp]
@@ -798,6 +803,7 @@ void launch_gemm_nt_splitk(T* C, int64_t ldc, const T* A, int64_t lda, const T* 
 template <typename T>
 void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                     int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st) {
+  debug_delay(st);
   if (m <= 0 || n <= 0) return;
   static const bool tall = [] {
     const char* e = getenv("GPX_SYRK_TALL");
@@ -821,6 +827,7 @@ void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const 
 template <typename T>
 void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
                        int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c, hipStream_t st) {
+  debug_delay(st);
   if (m <= 0 || n <= 0) return;
   const BcMask bc{bc_P, bc_tpb, bc_c};
   const int64_t tm = m / 128, tn = n / 128;
@@ -838,6 +845,7 @@ void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, i
 template <typename T>
 void launch_gemm_nn(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
                     int64_t n, int64_t k, hipStream_t st) {
+  debug_delay(st);
   if (m <= 0 || n <= 0) return;
   const int64_t tm = m / 64, tn = n / 64;
   int sh;

@@ -76,6 +76,9 @@ void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const 
                     int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st);
 // Sharded trailing update: C (m local rows x n, 128-tiles) -= A B^T restricted to tiles with
 //   tile_col <= ((tile_row / tpb) * P + c) * tpb + tile_row % tpb   (block-cyclic rows).
+// test hook: random spin kernels in front of launches (gpx_debug_set_delay; gpx_misc.hip)
+void debug_set_delay(uint64_t seed);
+void debug_delay(hipStream_t st);
 // C (m x n) = A (m x k) B(n x k)^T for skinny C with a long contraction (m, n multiples of 64): S
 // splits of k into partial tiles part[s] (m x ldp each, back to back), summed in split order
 int splitk_splits(int64_t k);  // depends on k only: batching the columns must not change the bits

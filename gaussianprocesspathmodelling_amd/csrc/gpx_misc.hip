@@ -4,6 +4,8 @@
 // rooflines.
 #include "gpx_internal.h"
 
+#include <atomic>
+
 namespace gpx {
 namespace {
 
@@ -310,9 +312,44 @@ void launch_var_rows(const T* VT, int64_t ld, int64_t m, int64_t ncols, double s
   hipLaunchKernelGGL(var_rows_kernel<T>, dim3((unsigned)m), dim3(256), 0, st, VT, ld, ncols, sf2, var);
 }
 
+// ---- timing perturbation (test hook) -------------------------------------------------------------
+// Every result of this library is deterministic whatever the relative timing of its streams — IF
+// every cross-stream dependency is expressed.  gpx_debug_set_delay(seed != 0) makes the launchers
+// put a short spin kernel (0..~170 us, one wave, bounded by the shader clock) in front of a random
+// third of their launches, on the stream of that launch: streams then race each other differently
+// on every seed, and a missing event shows up as a result that changes (tests/test_delay_gpu.py
+// demands bit-identical outputs).  Off (seed 0) it is one relaxed atomic load per launch.
+namespace {
+std::atomic<uint64_t> g_delay_state{0};
+__global__ void spin_kernel(long long cycles) {
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  while (__builtin_amdgcn_s_memtime() - t0 < cycles) {
+  }
+}
+}  // namespace
+
+void debug_set_delay(uint64_t seed) { g_delay_state.store(seed); }
+
+void debug_delay(hipStream_t st) {
+  uint64_t x = g_delay_state.load(std::memory_order_relaxed);
+  if (x == 0) return;
+  uint64_t nx;
+  do {  // xorshift64*, advanced atomically (rank threads of a group launch concurrently)
+    nx = x;
+    nx ^= nx >> 12;
+    nx ^= nx << 25;
+    nx ^= nx >> 27;
+    if (nx == 0) nx = 0x9E3779B97F4A7C15ull;
+  } while (!g_delay_state.compare_exchange_weak(x, nx, std::memory_order_relaxed));
+  const uint64_t r = nx * 0x2545F4914F6CDD1Dull;
+  if ((r >> 60) % 3 != 0) return;
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, (long long)((r >> 20) % 400000));
+}
+
 template <typename T>
 void launch_copy2d(T* dst, int64_t ldd, const T* src, int64_t lds, int64_t rows, int64_t cols, hipStream_t st) {
   if (rows <= 0 || cols <= 0) return;
+  debug_delay(st);
   const int64_t total = rows * (cols * (int64_t)sizeof(T) / 16);
   const int64_t bx = (total + 255) / 256;
   hipLaunchKernelGGL(copy2d_kernel<T>, dim3((unsigned)(bx > 8192 ? 8192 : bx)), dim3(256), 0, st, dst, ldd, src, lds, rows, cols);

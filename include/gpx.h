@@ -211,6 +211,11 @@ int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t 
 int gpx_debug_local_hub(int32_t P, int32_t rounds, int32_t abort_rank, int32_t abort_round,
                         int32_t* completed);
 
+/* Test hook (process-wide): seed != 0 puts a short bounded spin kernel in front of a random third
+ * of the library's launches, on the stream of that launch, so that its streams race each other
+ * differently per seed; 0 turns it off.  Results must not change by a bit — every cross-stream
+ * dependency is an event (tests/test_delay_gpu.py). */
+int gpx_debug_set_delay(uint64_t seed);
 /* Diagnostics: the dense tile engine alone, operands resident in HBM (zero-filled): C (n,n) -= / =
  * A (n,k) B(n,k)^T, lower != 0: the triangular (SYRK-shaped) launch of the trailing update; mode 0:
  * C -= (atomic epilogue), 1: C = (plain stores).  dtype GPX_F64 / GPX_F32; n multiple of 128,

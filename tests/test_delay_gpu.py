@@ -1,0 +1,52 @@
+"""GPU: results must not depend on the relative timing of the library's streams (main, look-ahead,
+side stream of the block inverses, copy stream; per rank in a device group).  gpx_debug_set_delay
+puts bounded spin kernels in front of a random third of all launches; every fit / predict /
+gradient below must come out BIT-identical to the undisturbed run — a dependency that is only
+satisfied by luck shows up as a changed bit."""
+import numpy as np
+import pytest
+
+from gaussianprocesspathmodelling_amd import GP, _abi
+from oracle.gp_oracle import synthetic_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def delay():
+    lib = _abi.load()
+    yield lambda seed: lib.gpx_debug_set_delay(seed)
+    lib.gpx_debug_set_delay(0)
+
+
+def run(N, M, kw, grad):
+    X, y, Xs = synthetic_problem(N, 3, M, seed=N)
+    with GP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0, **kw) as gp:
+        mean, var = gp.fit(X, y).predict(Xs)
+        out = [mean, var, gp.alpha_.copy(), np.float64(gp.log_det_), gp.predict(Xs, return_var=False)]
+        if grad:
+            lml, g = gp.lml_gradient()
+            out += [np.float64(lml), g]
+    return out
+
+
+@pytest.mark.parametrize("N,M,kw,grad,small", [
+    (5000, 700, {}, True, False),                            # 5 panels: look-ahead, block inverses, copy stream
+    (3000, 300, {"block": 256}, True, False),                # 12 narrow panels
+    (9000, 9000, {}, False, False),                          # 9 panels of 1024, two batches of query points
+    (2600, 200, {"devices": 3, "oversubscribe": True}, False, True),    # device group, distributed solves
+    (2600, 200, {"devices": 4, "oversubscribe": True}, True, True),     # device group, replicated factor + sharded gradient
+    (9000, 300, {"devices": 2, "oversubscribe": True}, False, False),   # device group, library-chosen 1024-blocks
+])
+def test_results_do_not_depend_on_stream_timing(monkeypatch, delay, N, M, kw, grad, small):
+    if small:
+        monkeypatch.setenv("GPX_NB_SHARD", "256")
+        monkeypatch.setenv("GPX_NB_PRED", "256")
+        monkeypatch.setenv("GPX_SHARD_REPLICATE", "1" if grad else "0")
+    base = run(N, M, kw, grad)
+    for seed in (1, 7, 123456789, 2024, 99):
+        delay(seed)
+        got = run(N, M, kw, grad)
+        delay(0)
+        for a, b in zip(base, got):
+            assert np.array_equal(a, b), f"seed {seed}: a result changed under timing perturbation"
