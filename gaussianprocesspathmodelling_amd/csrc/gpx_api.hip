@@ -1427,7 +1427,7 @@ int gpx_gemm_nt(double* C, int64_t m, int64_t n, const double* A, const double* 
   TCHK(hipMemcpy2DAsync(dC, (size_t)ldc * 8, C, (size_t)n * 8, (size_t)n * 8, (size_t)m, hipMemcpyHostToDevice, st));
   TCHK(hipMemcpy2DAsync(dA, (size_t)lda * 8, A, (size_t)k * 8, (size_t)k * 8, (size_t)m, hipMemcpyHostToDevice, st));
   TCHK(hipMemcpy2DAsync(dB, (size_t)lda * 8, B, (size_t)k * 8, (size_t)k * 8, (size_t)n, hipMemcpyHostToDevice, st));
-  launch_gemm_nt(tile, dC, ldc, dA, lda, dB, lda, m, n, k, lower, 0, st);
+  launch_gemm_nt_fixed(tile, dC, ldc, dA, lda, dB, lda, m, n, k, lower, 0, st);
   TCHK(hipMemcpy2DAsync(C, (size_t)n * 8, dC, (size_t)ldc * 8, (size_t)n * 8, (size_t)m, hipMemcpyDeviceToHost, st));
   TCHK(hipStreamSynchronize(st));
   TCHK(hipGetLastError());
@@ -1527,10 +1527,10 @@ int gemm_bench_t(int64_t n, int64_t k, int32_t lower, int32_t mode, int32_t iter
   TCHK(hipMemsetAsync(dA, 0, (size_t)2 * n * lda * sizeof(T), st));
   TCHK(hipEventCreate(&e0));
   TCHK(hipEventCreate(&e1));
-  launch_gemm_nt<T>(128, dC, ldc, dA, lda, dA + n * lda, lda, n, n, k, lower, mode, st);
+  launch_gemm_nt_fixed<T>(128, dC, ldc, dA, lda, dA + n * lda, lda, n, n, k, lower, mode, st);
   TCHK(hipEventRecord(e0, st));
   for (int i = 0; i < iters; ++i)
-    launch_gemm_nt<T>(128, dC, ldc, dA, lda, dA + n * lda, lda, n, n, k, lower, mode, st);
+    launch_gemm_nt_fixed<T>(128, dC, ldc, dA, lda, dA + n * lda, lda, n, n, k, lower, mode, st);
   TCHK(hipEventRecord(e1, st));
   TCHK(hipStreamSynchronize(st));
   TCHK(hipGetLastError());

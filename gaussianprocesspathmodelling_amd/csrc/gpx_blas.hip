@@ -801,8 +801,8 @@ void launch_gemm_nt_splitk(T* C, int64_t ldc, const T* A, int64_t lda, const T* 
 }
 
 template <typename T>
-void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
-                    int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st) {
+void launch_gemm_nt_fixed(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
+                          int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st) {
   debug_delay(st);
   if (m <= 0 || n <= 0) return;
   static const bool tall = [] {
@@ -822,6 +822,27 @@ void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const 
     launch_gemm_nt_t<T, 128>(C, ldc, A, lda, B, ldb, m, n, k, lower, mode, bc, st);
   else
     launch_gemm_nt_t<T, 64>(C, ldc, A, lda, B, ldb, m, n, k, lower, mode, bc, st);
+}
+
+// The library's own products: `tile` is the largest tile the shape allows; a 128-tile grid that
+// does not even fill the 512 workgroup slots once (strips and trailing updates of the last panels,
+// everything at N <= 8192) leaves CUs idle or half occupied, and the same product in 64-tiles has
+// four times the workgroups.  N = 8192: Cholesky 10.7 -> 10.35 ms; no effect at N = 65536
+// (measured: switching at 320 / 448 / 512 / 768 live tiles all within noise of each other).  With a
+// triangular mask the 64-tile grid leaves the upper 64-blocks of the diagonal 128-tiles untouched:
+// nothing reads them (only the lower triangle of the Gram matrix is ever read).
+template <typename T>
+void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
+                    int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st) {
+  constexpr int64_t thr = 448;
+  if (tile == 128 && lower != 4) {
+    const int64_t tm = m / 128, tn = n / 128;
+    const int64_t live = lower == 1   ? tm * (tm + 1) / 2
+                         : lower == 2 ? tm * tn - std::min(tm, tn) * (std::min(tm, tn) - 1) / 2 - (tn > tm ? (tn - tm) * tm : 0)
+                                      : tm * tn;
+    if (live <= thr) tile = 64;
+  }
+  launch_gemm_nt_fixed<T>(tile, C, ldc, A, lda, B, ldb, m, n, k, lower, mode, st);
 }
 
 template <typename T>
@@ -909,6 +930,8 @@ extern "C" int gpx_debug_read_syrk_clock(long long* out) {
                                      hipStream_t);                                                      \
   template void launch_gemm_nt<T>(int, T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,      \
                                   int64_t, int64_t, int, int, hipStream_t);                             \
+  template void launch_gemm_nt_fixed<T>(int, T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t, \
+                                        int64_t, int64_t, int, int, hipStream_t);                       \
   template void launch_gemm_nt_bc<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,        \
                                      int64_t, int64_t, int, int, int, hipStream_t);                     \
   template void launch_gemm_nn<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t, int64_t,  \

@@ -74,6 +74,10 @@ void launch_trsm_rln(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
 template <typename T>
 void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                     int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st);
+// the same with the tile size taken literally (unit-test entry point, engine benchmark)
+template <typename T>
+void launch_gemm_nt_fixed(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
+                    int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st);
 // Sharded trailing update: C (m local rows x n, 128-tiles) -= A B^T restricted to tiles with
 //   tile_col <= ((tile_row / tpb) * P + c) * tpb + tile_row % tpb   (block-cyclic rows).
 // test hook: random spin kernels in front of launches (gpx_debug_set_delay; gpx_misc.hip)
