@@ -827,17 +827,19 @@ void launch_gemm_nt_fixed(int tile, T* C, int64_t ldc, const T* A, int64_t lda, 
 // The library's own products: `tile` is the largest tile the shape allows; a 128-tile grid that
 // does not even fill the 512 workgroup slots once (strips and trailing updates of the last panels,
 // everything at N <= 8192) leaves CUs idle or half occupied, and the same product in 64-tiles has
-// four times the workgroups.  N = 8192: Cholesky 10.7 -> 10.35 ms; no effect at N = 65536
-// (measured: switching at 320 / 448 / 512 / 768 live tiles all within noise of each other).  With a
+// four times the workgroups.  N = 8192: Cholesky 10.7 -> 10.35 ms, and 10.05 ms with the products
+// against the block inverses (lower == 4) included, variance solve 5.45 -> 5.15 ms; no effect at
+// N = 65536 (measured: switching at 320 / 448 / 512 / 768 live tiles all within noise).  With a
 // triangular mask the 64-tile grid leaves the upper 64-blocks of the diagonal 128-tiles untouched:
 // nothing reads them (only the lower triangle of the Gram matrix is ever read).
 template <typename T>
 void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                     int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st) {
   constexpr int64_t thr = 448;
-  if (tile == 128 && lower != 4) {
+  if (tile == 128) {
     const int64_t tm = m / 128, tn = n / 128;
     const int64_t live = lower == 1   ? tm * (tm + 1) / 2
+                         : lower == 4 ? tm * ((tn + 1) / 2)
                          : lower == 2 ? tm * tn - std::min(tm, tn) * (std::min(tm, tn) - 1) / 2 - (tn > tm ? (tn - tm) * tm : 0)
                                       : tm * tn;
     if (live <= thr) tile = 64;
