@@ -28,8 +28,9 @@ N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU.
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline     — the dominant kernel (trailing SYRK of the blocked Cholesky, fp64 MFMA):
                  algorithmic flops n(n+1)nb per launch / hipEvent time per launch, both
-                 summed over the launches of the timed steps (library events on the
-                 library's stream, GPX_FLAG_PROFILE)
+                 summed over the launches of that kernel in the timed steps (library events
+                 on the library's stream, GPX_FLAG_PROFILE; the last few, under-filled
+                 updates of a fit run as 64-tiles — another kernel — and are not counted)
   cpu_baseline — the NumPy/SciPy oracle (oracle/gp_oracle.py) timed on this host's cores
                  on a bounded sample (N=24576, same generator, ~20 s), rank 0, N=1 only; BLAS
                  threads = the CPUs this process may use (affinity and cgroup quota), and

@@ -375,11 +375,16 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     }
     HIPCHK(h, hipEventRecord(e_panel, s1));
     if (nrest > 0) {  // REST: lower triangle of the trailing matrix beyond the strip
-      PhaseScope ps(h, &h->tm.chol_syrk, profile);
+      // the roofline bookkeeping (time, flops, launches) follows ONE kernel, the 128-tile triangular
+      // update; the last few, under-filled updates run as 64-tiles and are booked with the strips
+      const bool big = gemm_nt_tile(tile, nrest, nrest, 1) == 128;
+      PhaseScope ps(h, big ? &h->tm.chol_syrk : &h->tm.chol_strip, profile);
       launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + (t0 + nbn), ld, Pc + (int64_t)nbn * ldp, ldp,
                         Pc + (int64_t)nbn * ldp, ldp, nrest, nrest, nbp, 1, 0, s0);
-      h->tm.syrk_flops += (double)nrest * (double)(nrest + 1) * (double)nbp;
-      h->tm.syrk_launches += 1;
+      if (big) {
+        h->tm.syrk_flops += (double)nrest * (double)(nrest + 1) * (double)nbp;
+        h->tm.syrk_launches += 1;
+      }
     }
     HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
   }

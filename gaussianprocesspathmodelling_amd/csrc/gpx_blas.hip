@@ -832,19 +832,21 @@ void launch_gemm_nt_fixed(int tile, T* C, int64_t ldc, const T* A, int64_t lda, 
 // N = 65536 (measured: switching at 320 / 448 / 512 / 768 live tiles all within noise).  With a
 // triangular mask the 64-tile grid leaves the upper 64-blocks of the diagonal 128-tiles untouched:
 // nothing reads them (only the lower triangle of the Gram matrix is ever read).
+int gemm_nt_tile(int tile, int64_t m, int64_t n, int lower) {
+  constexpr int64_t thr = 448;
+  if (tile != 128) return tile;
+  const int64_t tm = m / 128, tn = n / 128;
+  const int64_t live = lower == 1   ? tm * (tm + 1) / 2
+                       : lower == 4 ? tm * ((tn + 1) / 2)
+                       : lower == 2 ? tm * tn - std::min(tm, tn) * (std::min(tm, tn) - 1) / 2 - (tn > tm ? (tn - tm) * tm : 0)
+                                    : tm * tn;
+  return live <= thr ? 64 : 128;
+}
+
 template <typename T>
 void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                     int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st) {
-  constexpr int64_t thr = 448;
-  if (tile == 128) {
-    const int64_t tm = m / 128, tn = n / 128;
-    const int64_t live = lower == 1   ? tm * (tm + 1) / 2
-                         : lower == 4 ? tm * ((tn + 1) / 2)
-                         : lower == 2 ? tm * tn - std::min(tm, tn) * (std::min(tm, tn) - 1) / 2 - (tn > tm ? (tn - tm) * tm : 0)
-                                      : tm * tn;
-    if (live <= thr) tile = 64;
-  }
-  launch_gemm_nt_fixed<T>(tile, C, ldc, A, lda, B, ldb, m, n, k, lower, mode, st);
+  launch_gemm_nt_fixed<T>(gemm_nt_tile(tile, m, n, lower), C, ldc, A, lda, B, ldb, m, n, k, lower, mode, st);
 }
 
 template <typename T>

@@ -74,6 +74,8 @@ void launch_trsm_rln(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
 template <typename T>
 void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                     int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st);
+// the tile size launch_gemm_nt really uses for (tile, m, n, lower): 64 when the 128-grid is under-filled
+int gemm_nt_tile(int tile, int64_t m, int64_t n, int lower);
 // the same with the tile size taken literally (unit-test entry point, engine benchmark)
 template <typename T>
 void launch_gemm_nt_fixed(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,

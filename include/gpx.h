@@ -90,7 +90,9 @@ typedef struct gpx_timings {
   double comm;                                                 /* RCCL time inside chol (sharded) */
   /* Cholesky sub-phases, filled only with GPX_FLAG_PROFILE: */
   double chol_diag, chol_trsm, chol_strip, chol_syrk; /* summed ms (diag/trsm run on the look-ahead stream) */
-  double syrk_flops;                       /* algorithmic flops of all SYRK launches: n(n+1) nb each */
+  double syrk_flops;                       /* algorithmic flops n(n+1) nb of the 128-tile trailing-update launches \
+                                              (chol_syrk / syrk_launches cover the same launches; the last few,     \
+                                              under-filled updates run as 64-tiles and are booked under chol_strip) */
   int64_t syrk_launches;
   double kbuild_bytes;                     /* algorithmic bytes of the kernel build */
   double grad_trtri, grad_trace, grad_total; /* gpx_lml_grad: L^-T build, fused K^-1 trace pass, whole call */
