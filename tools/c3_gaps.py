@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Where the factorisation at C3 is NOT running its big kernels: from a rocprofv3 kernel trace of
+bench.py (tools/c3_trace.sh), the idle time of the main stream's STRIP / REST sequence per panel
+(the part of the look-ahead chain the trailing update does not hide).
+    python tools/c3_gaps.py gpurun_out/c3trace/trace.csv"""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows:
+    r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+rows.sort(key=lambda r: r["s"])
+ks = [i for i, r in enumerate(rows) if "kbuild_kernel<double, 0, true" in r["Kernel_Name"]]
+ke = [i for i, r in enumerate(rows) if "kbuild_kernel<double, 0, false" in r["Kernel_Name"]]
+a, b = ks[-2] if len(ks) > 1 else ks[-1], None
+b = [i for i in ke if i > a][0]
+fit = rows[a:b]
+big = [r for r in fit if "gemm_nt_kernel<double, 128, true, 0>" in r["Kernel_Name"]]   # the trailing updates (REST)
+print("REST launches found:", len(big), " fit span %.1f ms" % ((fit[-1]["e"] - fit[0]["s"]) / 1e6))
+tot_rest = sum(r["e"] - r["s"] for r in big)
+gaps = [(big[i + 1]["s"] - big[i]["e"]) / 1e3 for i in range(len(big) - 1)]
+print("sum REST %.1f ms; sum of gaps between consecutive REST launches %.1f ms (STRIP + exposed chain)" % (tot_rest / 1e6, sum(gaps) / 1e3))
+for i in range(0, len(gaps), 8):
+    print("panels %2d..%2d gap us:" % (i, min(i + 7, len(gaps) - 1)), " ".join(f"{g:7.0f}" for g in gaps[i:i + 8]),
+          "| REST ms:", " ".join(f"{(big[k]['e'] - big[k]['s']) / 1e6:5.1f}" for k in range(i, min(i + 8, len(big)))))
+print("before first REST %.2f ms, after last REST %.2f ms" % ((big[0]["s"] - fit[0]["s"]) / 1e6, (fit[-1]["e"] - big[-1]["e"]) / 1e6))
