@@ -15,11 +15,19 @@ N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU.
       RCCL with one-panel look-ahead, value = (N+M) / max-over-ranks time, ``"scaling":
       "strong"``.  The sharded run lives in a CHILD process per rank (this process touches
       no GPU meanwhile) that writes a heartbeat and checks its posterior against the
-      single-GPU path on rank 0 (``shard_check``).  A child that fails, stalls or disagrees is a
-      FAILED run: rank 0 prints the JSON line with ``"value": null`` and the reason (with the
-      last heartbeat stage of the rank that noticed), and every rank exits non-zero.  Nothing is
-      substituted for the graded number.
+      single-GPU path on rank 0 (``shard_check``).  A child that fails, stalls or disagrees fails
+      that attempt.  The sequence is shard -> group -> fail: after a failed ``shard`` attempt the SAME
+      schedule (same kernels, panels, metric) is tried once more over its other transport
+      (``--mode group``: rank 0's child drives all N GPUs as one in-process device group over peer
+      copies and hipEvents — no RCCL, no inter-process IPC; the other ranks only keep time, so that
+      line is clocked on rank 0 alone and says so: ``timed_on``, ``fallback_from``).  If that fails
+      too, rank 0 prints the JSON line with ``"value": null`` and both reasons, and every rank exits
+      non-zero.  Nothing else (no replicas number) is ever substituted for the graded number.
+      NOTE: RCCL with more than one rank, and peer copies between distinct devices, have only ever
+      run where the driver runs this file on a multi-GPU node (the development boxes have one GPU);
+      the line carries ``"multi_gpu_transport_verified_on_hardware": false`` until a SCALE record exists.
   --mode shard: the sharded run in-process (what the child executes).
+  --mode group: rank 0 drives all N GPUs from one process (see above).
       ``--workload C4`` = N=262144, d=3, Matern-5/2 (needs 8 GPUs; no single-GPU check).
   --mode replicas: every rank runs its own replica of the workload (independent GPs, e.g.
       one per path cluster: no data-path collective), value = points of all ranks /
@@ -31,10 +39,13 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                  summed over the launches of that kernel in the timed steps (library events
                  on the library's stream, GPX_FLAG_PROFILE; the last few, under-filled
                  updates of a fit run as 64-tiles — another kernel — and are not counted)
-  cpu_baseline — the NumPy/SciPy oracle (oracle/gp_oracle.py) timed on this host's cores
-                 on a bounded sample (N=24576, same generator, ~20 s), rank 0, N=1 only; BLAS
-                 threads = the CPUs this process may use (affinity and cgroup quota), and
-                 ``cores`` is exactly that thread count
+  cpu_baseline — the NumPy/SciPy oracle (oracle/gp_oracle.py) on the GPU box's host cores.
+                 ``value`` is the rate AT THE WORKLOAD (N=65536): the full-size oracle run that
+                 also wrote the committed golden fixture (oracle/make_golden_full.py, ~2 min with 16
+                 threads; record under profiles/, or re-measured live with --cpu-baseline-full);
+                 ``live_sample`` is the bounded run of every bench invocation (N=24576, same
+                 generator, ~20 s) with its phase-wise extrapolation as a cross-check.  BLAS threads
+                 = the CPUs the process may use (affinity and cgroup quota) = ``cores``
 """
 from __future__ import annotations
 
@@ -114,22 +125,45 @@ def cpu_budget():
 
 
 def full_size_oracle_record():
-    """The one measured FULL-size oracle run (tools/full_oracle_c3.py writes it under profiles/)."""
+    """The measured FULL-size oracle run on a GPU box's host (oracle/make_golden_full.py --config C3
+    prints it; committed under profiles/ next to the golden fixture it produced)."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_full_oracle_parity.json")), reverse=True):
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_full_oracle_c3.json")), reverse=True) + \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_full_oracle_parity.json")), reverse=True)
+    for f in cands:
         try:
             with open(f) as fh:
                 rec = json.load(fh)
             if "oracle_points_per_s" in rec:
-                return {"file": os.path.basename(f), "points_per_s": rec["oracle_points_per_s"],
-                        "seconds": rec.get("oracle_fit_predict_s"), "threads": rec.get("blas_threads")}
+                return {"file": "profiles/" + os.path.basename(f), "points_per_s": rec["oracle_points_per_s"],
+                        "seconds": rec.get("oracle_fit_predict_s"), "threads": rec.get("blas_threads"),
+                        "cholesky_s": rec.get("oracle_cholesky_s")}
         except Exception:
             pass
     return None
 
 
-def cpu_baseline(n_sample=24576):
-    """Oracle fit+predict on the host cores, bounded sample (about 10-30 s).
+def cpu_full_size_live():
+    """--cpu-baseline-full: the oracle at the workload's own size, now, on this host (34.4 GB, minutes)."""
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), f"gpx_g5_{os.getpid()}.npz")
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_golden_full.py"), "--config", "C3",
+                            "--out", out], capture_output=True, text=True, check=True)
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"file": "live (--cpu-baseline-full)", "points_per_s": rec["oracle_points_per_s"],
+                "seconds": rec["oracle_fit_predict_s"], "threads": rec["blas_threads"],
+                "cholesky_s": rec["oracle_cholesky_s"]}
+    finally:
+        if os.path.exists(out):
+            os.remove(out)
+
+
+def cpu_baseline(n_sample=24576, full_live=False):
+    """`value` = the oracle's fit+predict rate AT THE WORKLOAD (N=65536), measured at full size on a GPU
+    box's host cores (committed record, or live with --cpu-baseline-full); `live_sample` = the bounded
+    run of this invocation (about 10-30 s) and its phase-wise extrapolation, as a cross-check.
 
     The BLAS pools are limited to the CPUs this process may really use (affinity, cgroup
     quota): a pool larger than the quota — the default is 64 threads on this pool's hosts
@@ -155,23 +189,30 @@ def cpu_baseline(n_sample=24576):
     est = (tm["kbuild"] * r ** 2 + tm["chol"] * r ** 3 + tm["solve"] * r ** 2
            + (tm["kstar"] + tm["mean"]) * r + (tm["trsm"] + tm["var"]) * r ** 2) * 1e-3
     chol_gf = n_sample ** 3 / 3.0 / (tm["chol"] * 1e-3) / 1e9
-    full = full_size_oracle_record()
+    full = cpu_full_size_live() if full_live else full_size_oracle_record()
+    live = {"N": n_sample, "points_per_s": (n_sample + M_TEST) / (t2 - t0), "fit_s": t1 - t0, "predict_s": t2 - t1,
+            "cholesky_gflops": chol_gf, "threads": threads,
+            "extrapolated_seconds_at_workload": est,
+            "extrapolated_points_per_s_at_workload": (N_TRAIN + M_TEST) / est}
+    if full:
+        value, cores = full["points_per_s"], full["threads"] or threads
+        how = (f"FULL workload N={N_TRAIN} d={DIM} M={M_TEST} RBF fp64, same generator, measured once at full size on a "
+               f"GPU box's host with {cores} BLAS threads ({full['file']}: {full['seconds']:.1f} s per fit+predict, "
+               f"Cholesky {full['cholesky_s']:.1f} s); this run's bounded live sample (N={n_sample}, {t2 - t0:.1f} s) "
+               f"extrapolates phase-wise to {(N_TRAIN + M_TEST) / est:.0f} points/s")
+    else:
+        value, cores = (N_TRAIN + M_TEST) / est, threads
+        how = (f"no full-size record committed: phase-wise EXTRAPOLATION to N={N_TRAIN} of a live N={n_sample} sample "
+               f"({t2 - t0:.1f} s)")
     return {
-        "value": (n_sample + M_TEST) / (t2 - t0), "unit": "points/s", "cores": threads,
-        "kind": "port",
-        "sample": (f"oracle/gp_oracle.py (NumPy/SciPy; level-3 blocked Cholesky — LAPACK potrf of the bundled "
-                   f"OpenBLAS does not parallelise) full fit+predict at N={n_sample} (NOT the workload's "
-                   f"N={N_TRAIN}) d={DIM} M={M_TEST} RBF fp64, same generator, {threads} BLAS threads: fit "
-                   f"{t1 - t0:.2f} s (kbuild {tm['kbuild']:.0f} ms, chol {tm['chol']:.0f} ms = {chol_gf:.0f} GF/s, "
-                   f"solve {tm['solve']:.0f} ms), predict {t2 - t1:.2f} s; EXTRAPOLATED phase-wise to the "
-                   f"workload N={N_TRAIN}: {est:.0f} s/step = {(N_TRAIN + M_TEST) / est:.1f} points/s"
-                   + (f"; measured full-size run ({full['file']}): {full['points_per_s']:.1f} points/s" if full else "")),
+        "value": value, "unit": "points/s", "cores": cores, "kind": "port",
+        "sample": "oracle/gp_oracle.py (NumPy/SciPy; level-3 blocked Cholesky — LAPACK potrf of the bundled OpenBLAS "
+                  "does not parallelise): " + how,
+        "at_workload": bool(full), "measured_full_size": full, "live_sample": live,
         "host": {"os_cpu_count": os.cpu_count(), "affinity_cpus": aff, "cgroup_cpu_quota": quota,
                  "blas_pools": [f"{p.get('internal_api')} {p.get('version')}: {p.get('num_threads')} threads by default"
                                 for p in pools if p.get("user_api") == "blas"],
                  "blas_threads_used": threads},
-        "extrapolated_points_per_s_at_workload": (N_TRAIN + M_TEST) / est,
-        "measured_full_size": full,
     }
 
 
@@ -194,6 +235,8 @@ def main():
                     help="gloo = rehearsal of the multi-rank code on one GPU (host collectives)")
     ap.add_argument("--device", type=int, default=None, help="HIP device override (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="re-measure the full-size (N=65536) CPU oracle live (about 2-3 minutes, 35 GB of host memory)")
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -406,6 +449,7 @@ def run(args):
         elapsed = float(t.item())
     ok = True if gp is None else bool(torch.isfinite(mean).all().item() and (var > 0).all().item())
     pcie_ms = None
+    unprofiled_ms = None
     if world == 1 and not shard:
         # the same step with HOST NumPy arrays in and out (H2D of X, y, Xs and D2H of mean, var inside
         # the clock): never `value`, stated once beside it
@@ -413,6 +457,23 @@ def run(args):
         t1 = time.perf_counter()
         gp.fit(X, y).predict(Xs)
         pcie_ms = (time.perf_counter() - t1) * 1e3
+        # what GPX_FLAG_PROFILE (a hipEvent pair around every Cholesky sub-phase launch inside the timed
+        # region: the roofline's live clock) costs: the same step on a handle without the flag
+        with GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=False) as plain:
+            plain.fit(Xd, yd).predict(Xsd)
+            torch.cuda.synchronize(dev)
+            nrep = max(1, min(3, args.steps))
+            t_plain = t_prof = 0.0
+            for _ in range(nrep):               # interleaved: the card's clock drifts as it warms up
+                for which in (plain, gp):
+                    t1 = time.perf_counter()
+                    which.fit(Xd, yd).predict(Xsd)
+                    torch.cuda.synchronize(dev)
+                    if which is plain:
+                        t_plain += time.perf_counter() - t1
+                    else:
+                        t_prof += time.perf_counter() - t1
+            unprofiled_ms = (t_plain * 1e3 / nrep, t_prof * 1e3 / nrep)
     shard_check = None
     if shard and N <= 131072:
         # the sharded posterior against the single-GPU path on the same inputs (rank 0's GPU)
@@ -453,6 +514,12 @@ def run(args):
             "value": (1 if shard else world) * (N + M) * steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3, "pcie_inclusive_ms_per_step": pcie_ms,
+            "profile_flag": None if unprofiled_ms is None else {
+                "ms_per_step_without": unprofiled_ms[0], "ms_per_step_with": unprofiled_ms[1],
+                "cost_ms_per_step": unprofiled_ms[1] - unprofiled_ms[0],
+                "note": "the timed steps run with GPX_FLAG_PROFILE (hipEvent pairs around the Cholesky sub-phase launches: "
+                        "the roofline's clock); measured after the timed region on two handles, steps interleaved "
+                        "(without, with, without, ...), so that clock drift hits both alike"},
             "higher_is_better": True,
             "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -465,6 +532,11 @@ def run(args):
                         else f"{world} independent replicas")},
             "outputs_finite": ok,
             "shard_check": shard_check,
+            **({"timed_on": "rank 0 only (its process drives all GPUs; the other ranks hold no GPU context and wait)" if group
+                else "max over ranks", "multi_gpu_transport_verified_on_hardware": False,
+                "panel_solve": "slab" if os.environ.get("GPX_SHARD_DENSE_PANEL") == "0" else
+                "dense (block inverse broadcast with the diagonal block: +nb^2 doubles per panel; GPX_SHARD_DENSE_PANEL=0 = slab)"}
+               if shard and world > 1 else {}),
             **({"fallback_from": os.environ["GPX_BENCH_FALLBACK_REASON"]} if group and os.environ.get("GPX_BENCH_FALLBACK_REASON") else {}),
             "phases_ms": phases,
             "roofline": {
@@ -492,7 +564,7 @@ def run(args):
             if _abi.load().gpx_microbench(C.byref(a), C.byref(b)) == 0:
                 out["microbench"] = {"mfma_f64_loop_tflops": a.value, "stream_copy_gbs": b.value}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(full_live=args.cpu_baseline_full)
         if world > 1:
             sync()
         print(json.dumps(out), flush=True)

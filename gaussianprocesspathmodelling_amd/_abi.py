@@ -10,11 +10,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgpx.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 KERNEL_IDS = {"rbf": 0, "matern52": 1}
 DTYPE_IDS = {"float64": 0, "float32": 1, "mixed": 2}
 MEM_HOST, MEM_DEVICE = 0, 1
+E_ARG, E_HIP, E_COMM, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4, -5
 FLAG_PROFILE = 1
 TRANSPORT_IDS = {None: 0, "auto": 0, "rccl": 1, "local": 2}
 MAX_GROUP = 8
@@ -34,7 +35,7 @@ class GpxTimings(C.Structure):
                  "comm", "chol_diag", "chol_trsm", "chol_strip", "chol_syrk", "syrk_flops")] + \
                [("syrk_launches", C.c_int64), ("kbuild_bytes", C.c_double)] + \
                [(n, C.c_double) for n in ("grad_trtri", "grad_trace", "grad_total", "refine", "refine_resid0",
-                                          "refine_resid")]
+                                          "refine_resid", "refine_iters")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

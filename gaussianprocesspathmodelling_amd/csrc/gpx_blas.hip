@@ -399,42 +399,19 @@ __device__ long long gpx_stamp_buf[64];
   } while (0)
 #endif
 
+// Factorisation + inverse of the 64x64 block held in LDS (the body shared by potf2_64_kernel and
+// potf2_128_kernel).  On entry Wk holds the block (lower triangle; whatever sits above the diagonal
+// is never used) and the caller has passed a barrier; Wi is scratch.  On return Wk = L (lower),
+// Wi = L^-1 (lower, strictly upper part zero), and a barrier has been passed.  stamp0 < 0: no stamps.
 template <typename T>
-__global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_t lda,
-                                                       T* __restrict__ Winv, int64_t gidx0,
-                                                       int* __restrict__ info) {
+__device__ __forceinline__ void potf2_lds(T* __restrict__ Wk, T* __restrict__ Wi, T* __restrict__ PB,
+                                          T* __restrict__ Tm, T* __restrict__ Rinv, int64_t gidx0,
+                                          int* __restrict__ info) {
   using v4 = typename Num<T>::v4;
-  __shared__ __attribute__((aligned(16))) T Wk[64 * PLD];  // working matrix -> L (lower)
-  __shared__ __attribute__((aligned(16))) T Wi[64 * PLD];  // inverse
-  __shared__ __attribute__((aligned(16))) T PB[64 * PW];   // current PW-column panel
-  __shared__ __attribute__((aligned(16))) T Tm[32 * TLD];  // product scratch
-  __shared__ T Rinv[64];                                    // 1 / L[i][i]
-  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const T zero = (T)0, one = (T)1;
-  GPX_STAMP(0);
-  {
-    // all 16 loads of a thread in flight before the first LDS write: the tile comes from HBM /
-    // Infinity Cache (the trailing update's atomics leave nothing in L2), and one dependent
-    // load -> ds_write pair per iteration serialised 16 misses (18 k of the kernel's 62 k cycles)
-    T v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e = tid + 256 * u, i = e >> 6, k = e & 63;
-      v[u] = (k <= i) ? A[(int64_t)i * lda + k] : zero;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int e = tid + 256 * u, i = e >> 6, k = e & 63;
-      Wk[i * PLD + k] = v[u];
-      Wi[i * PLD + k] = zero;
-    }
-  }
-  __syncthreads();
-  GPX_STAMP(1);
-
   for (int j = 0; j < 64; j += PW) {
     // ---- phase A: PW x PW diagonal factor (redundant per thread, right-looking in
     //      registers) + this thread's panel row
@@ -515,8 +492,16 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
     GPX_STAMP(3 + 2 * (j / PW));
   }
 
-  // ---- inverse, level 0: wave w inverts diagonal block w; lane c < 16 owns column c
+  // ---- inverse, level 0: wave w inverts diagonal block w; lane c < 16 owns column c.  The six
+  //      16x16 blocks above the block diagonal are zeroed here (level 2 reads two of them, and the
+  //      caller stores the whole 64x64 inverse): Wi needs no initialisation by the caller.
   {
+    for (int e = tid; e < 6 * 256; e += 256) {
+      const int bidx = e >> 8, w = e & 255;          // blocks (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+      const int br = bidx < 3 ? 0 : bidx < 5 ? 1 : 2;
+      const int bc = bidx < 3 ? bidx + 1 : bidx < 5 ? bidx - 1 : 3;
+      Wi[(br * 16 + (w >> 4)) * PLD + bc * 16 + (w & 15)] = zero;
+    }
     const int b0 = wave * 16;
     if (lane < 16) {
       T w[16];
@@ -577,6 +562,40 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
       Wi[(32 + tr * 16 + Num<T>::drow(l4, r)) * PLD + tc * 16 + l15] = -acc2[r];
   }
   __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_t lda,
+                                                       T* __restrict__ Winv, int64_t gidx0,
+                                                       int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) T Wk[64 * PLD];  // working matrix -> L (lower)
+  __shared__ __attribute__((aligned(16))) T Wi[64 * PLD];  // inverse
+  __shared__ __attribute__((aligned(16))) T PB[64 * PW];   // current PW-column panel
+  __shared__ __attribute__((aligned(16))) T Tm[32 * TLD];  // product scratch
+  __shared__ T Rinv[64];                                    // 1 / L[i][i]
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x;
+  const T zero = (T)0;
+  GPX_STAMP(0);
+  {
+    // all 16 loads of a thread in flight before the first LDS write: the tile comes from HBM /
+    // Infinity Cache (the trailing update's atomics leave nothing in L2), and one dependent
+    // load -> ds_write pair per iteration serialised 16 misses (18 k of the kernel's 62 k cycles)
+    T v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u, i = e >> 6, k = e & 63;
+      v[u] = (k <= i) ? A[(int64_t)i * lda + k] : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u, i = e >> 6, k = e & 63;
+      Wk[i * PLD + k] = v[u];
+    }
+  }
+  __syncthreads();
+  GPX_STAMP(1);
+  potf2_lds<T>(Wk, Wi, PB, Tm, Rinv, gidx0, info);
   GPX_STAMP(20);
   for (int e = tid; e < 4096; e += 256) {
     const int ii = e >> 6, k = e & 63;
@@ -584,6 +603,127 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
     Winv[e] = Wi[ii * PLD + k];
   }
   GPX_STAMP(21);
+}
+
+// ---- POTF2 of a 128x128 diagonal tile in ONE launch (round 3) ------------------------------------
+//   [A11     ]      L11 = chol(A11), W11 = L11^-1             (potf2_lds)
+//   [A21  A22]      L21 = A21 W11^T                            (MFMA, k limited to W11's triangle)
+//                   A22 <- A22 - L21 L21^T (lower 16-tiles)    (MFMA, A22 held in the accumulators)
+//                   L22 = chol(A22), W22 = L22^-1              (potf2_lds, buffers swapped)
+// The serial diagonal chain of a panel then runs ONE POTF2, ONE solve of the rows below, ONE in-block
+// update and ONE inverse-extension event per 128 columns instead of per 64 (the
+// chain, not the flops, is the time of a small problem — BASELINE.json configs[1]).  Same two
+// 64x66 LDS buffers as the 64-wide kernel, used in turn: U = A11 -> L11 -> A21 -> L21 -> W22,
+// V = W11 -> A22' -> L22.  All three input tiles are requested before the first factorisation, so the
+// second one never waits for memory.  Winv: the two 64x64 inverses, back to back.
+template <typename T>
+__global__ __launch_bounds__(256) void potf2_128_kernel(T* __restrict__ A, int64_t lda,
+                                                        T* __restrict__ Winv, int64_t gidx0,
+                                                        int* __restrict__ info) {
+  using v4 = typename Num<T>::v4;
+  __shared__ __attribute__((aligned(16))) T U[64 * PLD];
+  __shared__ __attribute__((aligned(16))) T V[64 * PLD];
+  __shared__ __attribute__((aligned(16))) T PB[64 * PW];
+  __shared__ __attribute__((aligned(16))) T Tm[32 * TLD];
+  __shared__ T Rinv[64];
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const T zero = (T)0;
+  T* A21 = A + (int64_t)64 * lda;
+  T* A22 = A21 + 64;
+  // lower 16-tiles of the 64x64 block A22, dealt over the waves: (tr, tc), tc <= tr, index idx -> wave idx & 3
+  T v11[16], v21[16];
+  v4 c22[3];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = tid + 256 * u, i = e >> 6, k = e & 63;
+    v11[u] = (k <= i) ? A[(int64_t)i * lda + k] : zero;
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = tid + 256 * u, i = e >> 6, k = e & 63;
+    v21[u] = A21[(int64_t)i * lda + k];
+  }
+  {
+    int idx = 0, slot = 0;
+    for (int tr = 0; tr < 4; ++tr)
+      for (int tc = 0; tc <= tr; ++tc, ++idx) {
+        if ((idx & 3) != wave) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = tr * 16 + Num<T>::drow(l4, r), col = tc * 16 + l15;
+          const T x = (col <= row) ? A22[(int64_t)row * lda + col] : zero;
+          if (slot == 0) c22[0][r] = x; else if (slot == 1) c22[1][r] = x; else c22[2][r] = x;
+        }
+        ++slot;
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = tid + 256 * u, i = e >> 6, k = e & 63;
+    U[i * PLD + k] = v11[u];
+  }
+  __syncthreads();
+  potf2_lds<T>(U, V, PB, Tm, Rinv, gidx0, info);  // U = L11, V = W11
+  for (int e = tid; e < 4096; e += 256) {
+    const int ii = e >> 6, k = e & 63;
+    if (k <= ii) A[(int64_t)ii * lda + k] = U[ii * PLD + k];
+    Winv[e] = V[ii * PLD + k];
+  }
+  __syncthreads();  // every read of L11 done: U becomes the staging buffer of A21
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int e = tid + 256 * u, i = e >> 6, k = e & 63;
+    U[i * PLD + k] = v21[u];
+  }
+  __syncthreads();
+  {
+    // L21 = A21 W11^T: wave w owns the 16-row strip w (tiles (w, 0..3)); W11[c][k] = 0 for k > c
+    v4 acc[4];
+#pragma unroll
+    for (int tc = 0; tc < 4; ++tc) {
+      acc[tc] = (v4){0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        if (ks < 4 * (tc + 1))
+          acc[tc] = Num<T>::mfma(U[(wave * 16 + l15) * PLD + ks * 4 + l4], V[(tc * 16 + l15) * PLD + ks * 4 + l4],
+                                 acc[tc]);
+    }
+    __syncthreads();  // every read of A21 (U) and W11 (V) done
+#pragma unroll
+    for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wave * 16 + Num<T>::drow(l4, r), col = tc * 16 + l15;
+        U[row * PLD + col] = acc[tc][r];
+        A21[(int64_t)row * lda + col] = acc[tc][r];
+      }
+  }
+  __syncthreads();
+  {
+    // A22 <- A22 - L21 L21^T on the lower 16-tiles; the result becomes the working matrix in V
+    int idx = 0, slot = 0;
+    for (int tr = 0; tr < 4; ++tr)
+      for (int tc = 0; tc <= tr; ++tc, ++idx) {
+        if ((idx & 3) != wave) continue;
+        v4 acc = slot == 0 ? c22[0] : slot == 1 ? c22[1] : c22[2];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+          acc = Num<T>::mfma(-U[(tr * 16 + l15) * PLD + ks * 4 + l4], U[(tc * 16 + l15) * PLD + ks * 4 + l4], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) V[(tr * 16 + Num<T>::drow(l4, r)) * PLD + tc * 16 + l15] = acc[r];
+        ++slot;
+      }
+  }
+  __syncthreads();
+  potf2_lds<T>(V, U, PB, Tm, Rinv, gidx0 + 64, info);  // V = L22, U = W22
+  for (int e = tid; e < 4096; e += 256) {
+    const int ii = e >> 6, k = e & 63;
+    if (k <= ii) A22[(int64_t)ii * lda + k] = V[ii * PLD + k];
+    Winv[4096 + e] = U[ii * PLD + k];
+  }
 }
 
 // ---- X <- X * L^-T (right, lower, transposed): ascending 64-column blocks --------------
@@ -743,6 +883,12 @@ template <typename T>
 void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st) {
   debug_delay(st);
   hipLaunchKernelGGL(potf2_64_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, Winv, gidx0, info);
+}
+
+template <typename T>
+void launch_potf2_128(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st) {
+  debug_delay(st);
+  hipLaunchKernelGGL(potf2_128_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, Winv, gidx0, info);
 }
 
 template <typename T>
@@ -927,6 +1073,7 @@ extern "C" int gpx_debug_read_syrk_clock(long long* out) {
 
 #define GPX_INSTANTIATE_BLAS(T)                                                                         \
   template void launch_potf2_64<T>(T*, int64_t, T*, int64_t, int*, hipStream_t);                        \
+  template void launch_potf2_128<T>(T*, int64_t, T*, int64_t, int*, hipStream_t);                       \
   template void launch_trsm_rlt<T>(T*, int64_t, int64_t, const T*, int64_t, const T*, int, T*, int64_t, \
                                    hipStream_t);                                                        \
   template void launch_trsm_rln<T>(T*, int64_t, int64_t, const T*, int64_t, const T*, int, hipStream_t); \

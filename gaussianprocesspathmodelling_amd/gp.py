@@ -36,15 +36,22 @@ class GP:
     jitter : extra diagonal term; default 1e-10 * variance
     dtype : "float64" | "float32" (everything, including the factorisation, in fp32:
         the precision study of BASELINE.json configs[4]; not a 1e-6 path) | "mixed" (float64 in and
-        out; the factorisation and the variance in fp32 at twice the MFMA rate, alpha refined in
-        fp64 against the matrix-free fp64 kernel, posterior mean in fp64; at most 8 targets)
-    refine : "mixed" only — refinement iterations (default 3)
+        out; the factorisation in fp32 at twice the MFMA rate, alpha refined in fp64 against the
+        matrix-free fp64 kernel: **fp64-grade posterior mean** (1e-6 elementwise at N = 65536,
+        tests/test_full_size_gpu.py) but an **fp32-grade variance** — sf2 - ||L^-1 k*||^2 through
+        the fp32 factor is never refined, so it carries absolute errors of ~3e-6 sf2, which is
+        percents of a variance of 1e-4 sf2; use "float64" when the variance matters.  At most 8
+        targets)
+    refine : "mixed" only — 0 (default): refine until ||y - K alpha|| <= 1e-10 ||y|| or the residual
+        stops contracting (at most 12 iterations; ``timings_["refine_iters"]`` says how many ran);
+        n > 0: exactly n iterations
     device : HIP device ordinal (default: LOCAL_RANK or 0)
     devices : several GPUs from ONE ordinary Python process: an int n (devices
         0..n-1) or a list of HIP ordinals.  The Gram matrix is sharded in block-cyclic row blocks
         over them; one worker thread per device lives inside ``fit`` / ``predict``, which stay
         plain blocking calls — no launcher, no ``torch.distributed``.  ``devices=1`` / ``[i]`` is
-        the single-GPU path on that device.
+        the single-GPU path on that device — unless ``transport`` is given explicitly: then it is a
+        ONE-rank group (the group / RCCL code path on a single GPU; tests).
     transport : how the devices of a ``devices=`` group exchange panels: "rccl"
         (``ncclCommInitAll`` inside the process; distinct devices only), "local" (peer copies
         and hipEvents between the ranks' streams, nothing but HIP), None/"auto" = rccl when the
@@ -83,6 +90,7 @@ class GP:
         self._np_dtype = np.float32 if dtype == "float32" else np.float64
         self.block = int(block)
         self.max_tries = int(max_tries)
+        self.refine = int(refine)
         if device is None:
             import os
             device = int(os.environ.get("LOCAL_RANK", "0"))
@@ -92,7 +100,8 @@ class GP:
         if transport not in _abi.TRANSPORT_IDS:
             raise ValueError(f"unknown transport {transport!r}; expected rccl / local / auto")
         self.devices = self._resolve_devices(devices, oversubscribe)
-        if len(self.devices) > 1 and (self.world != 1 or comm is not None):
+        self._is_group = len(self.devices) > 1 or (len(self.devices) == 1 and _abi.TRANSPORT_IDS[transport] != 0)
+        if self._is_group and (self.world != 1 or comm is not None):
             raise ValueError("devices= (one process, several GPUs) and world=/comm= (one process per GPU) "
                              "are two different process models: pick one")
         if self.devices:
@@ -272,7 +281,7 @@ class GP:
         so a hyper-parameter search is resumed by saving this after every ``optimize`` step."""
         st = {"format": 1, "kernel": self.kernel, "lengthscale": [float(v) for v in self.lengthscale],
               "variance": self.variance, "noise": self.noise, "jitter": self.jitter, "dtype": self.dtype,
-              "block": self.block, "max_tries": self.max_tries}
+              "block": self.block, "max_tries": self.max_tries, "refine": self.refine}
         if self._fitted:
             st["fitted"] = {"N": int(self._N), "d": int(self._d), "k": int(self._k),
                             "jitter_used": float(self.jitter_used_), "log_det": float(self.log_det_)}
@@ -285,6 +294,7 @@ class GP:
         if state.get("format") != 1:
             raise ValueError("not a GP state of this library (format 1)")
         kw = {k: state[k] for k in ("kernel", "variance", "noise", "jitter", "dtype", "block", "max_tries")}
+        kw["refine"] = state.get("refine", 0)
         ls = state["lengthscale"]
         kw["lengthscale"] = ls[0] if len(ls) == 1 else ls
         kw.update(overrides)
@@ -375,7 +385,7 @@ class GP:
 
         best = {"f": np.inf, "v": pack()}
         analytic = jac == "analytic" and self.dtype == "float64"
-        if analytic and (self.world > 1 or len(self.devices) > 1 or self._host_comm is not None):
+        if analytic and (self.world > 1 or self._is_group or self._host_comm is not None):
             # sharded: the gradient needs the replicated-factor mode, which the library picks from N
             # and the card's memory at fit time — ask it once (every rank gets the same answer)
             try:
@@ -390,13 +400,25 @@ class GP:
         for p in names:
             cols.extend(range(n_ls) if p == "lengthscale" else [n_ls + (0 if p == "variance" else 1)])
 
-        def objective(v):
+        class _NoAnalyticGradient(Exception):
+            pass
+
+        def objective(v, analytic):
             unpack(v)
             g = np.zeros(len(cols))
             try:
                 self.fit(X, y)
                 if analytic:
-                    lml, full = self.lml_gradient()
+                    try:
+                        lml, full = self.lml_gradient()
+                    except _abi.GpxError as e:
+                        # no gradient for this model after all (factor only held distributed, or no
+                        # room for the N x N L^-T buffer): free what the attempt allocated and let the
+                        # caller restart the search with central differences
+                        if e.code not in (_abi.E_UNSUPPORTED, _abi.E_NOMEM):
+                            raise
+                        self.release_scratch()
+                        raise _NoAnalyticGradient() from e
                     f, g = -lml, -full[cols]
                 else:
                     f = -self.log_marginal_likelihood(y)
@@ -410,10 +432,16 @@ class GP:
 
         v0 = pack()
         lo, hi = np.log(bounds[0]), np.log(bounds[1])
-        res = minimize(objective, v0, method="L-BFGS-B", jac=True if analytic else "3-point",
-                       bounds=[(lo, hi)] * v0.size,
-                       options={"maxiter": int(maxiter)} if analytic else
-                       {"maxiter": int(maxiter), "eps": float(rel_step)})
+
+        def search(start, analytic):
+            return minimize(objective, start, args=(analytic,), method="L-BFGS-B",
+                            jac=True if analytic else "3-point", bounds=[(lo, hi)] * v0.size,
+                            options={"maxiter": int(maxiter)} if analytic else
+                            {"maxiter": int(maxiter), "eps": float(rel_step)})
+        try:
+            res = search(v0, analytic)
+        except _NoAnalyticGradient:
+            res = search(best["v"], False)   # from the best point the analytic steps reached
         unpack(best["v"])
         self.fit(X, y)
         res.x, res.fun = best["v"], best["f"]

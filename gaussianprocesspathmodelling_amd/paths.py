@@ -277,6 +277,7 @@ def fit_path_models(trajs, clusters, inputs=("t",), targets=("x", "y"), devices=
     default: the current device), one host thread per device, no data-path collective.  With
     ``optimize`` the hyper-parameters of each model are fitted by :meth:`GP.optimize` (analytic
     gradient) first.  Returns {cluster id: :class:`PathModel`}; empty clusters are skipped."""
+    import threading
     from concurrent.futures import ThreadPoolExecutor
     from .gp import GP
     if devices is None:
@@ -322,13 +323,22 @@ def fit_path_models(trajs, clusters, inputs=("t",), targets=("x", "y"), devices=
     for i, (cid, keys) in enumerate(jobs):
         by_dev[i % len(devs)].append((i, cid, keys))
     models = {}
+    lock = threading.Lock()
+
+    def worker(lst):
+        # every model is filed the moment it exists: if a later cluster of this device raises, the
+        # ones already built are still in `models` and get closed below (their factors live on the GPU)
+        for i, c, k in lst:
+            cid, m = fit_one(i, c, k)
+            with lock:
+                models[cid] = m
+
     with ThreadPoolExecutor(max_workers=len(devs)) as pool:
-        futs = [pool.submit(lambda lst=lst: [fit_one(i, c, k) for i, c, k in lst]) for lst in by_dev if lst]
+        futs = [pool.submit(worker, lst) for lst in by_dev if lst]
         err = None
         for f in futs:
             try:
-                for cid, m in f.result():
-                    models[cid] = m
+                f.result()
             except Exception as e:                  # keep collecting so every handle gets closed
                 err = err or e
         if err is not None:

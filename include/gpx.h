@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GPX_ABI_VERSION 2
+#define GPX_ABI_VERSION 3
 
 /* kernel family — SURVEY.md §8 row a1 (nearest reference code: the pairwise
  * distance loop trajectories.calc_distance, GPmap.py:114-121, and the unused
@@ -36,8 +36,10 @@ extern "C" {
 
 #define GPX_F64 0
 #define GPX_F32 1
-#define GPX_MIXED 2 /* inputs / outputs double; factorisation and variance in fp32, alpha refined in \
-                       fp64 against the matrix-free fp64 kernel, posterior mean in fp64 (configs[4]) */
+#define GPX_MIXED 2 /* inputs / outputs double; factorisation in fp32, alpha refined in fp64 against the  \
+                       matrix-free fp64 kernel until ||y - K alpha|| <= 1e-10 ||y||: fp64-GRADE posterior \
+                       MEAN, fp32-GRADE VARIANCE (sf2 - ||L^-1 k*||^2 through the fp32 factor, never      \
+                       refined: errors of ~1e-6 sf2 absolute, i.e. percents of a small variance) (configs[4]) */
 
 #define GPX_MEM_HOST 0   /* pointers are host memory; library copies H2D/D2H   */
 #define GPX_MEM_DEVICE 1 /* pointers are device memory on the handle's device  */
@@ -75,10 +77,13 @@ typedef struct gpx_config {
    * the same row-block-cyclic schedule as the process-per-GPU shard.  gpx_fit / gpx_predict /
    * gpx_get_alpha / ... on the group handle are ordinary blocking calls of a plain caller (no
    * launcher, no torch.distributed); rank/world must be 0/1 then. */
-  int32_t ndev;                     /* 0 or 1: one device (`device`);  2..GPX_MAX_GROUP: group */
+  int32_t ndev;                     /* 0 or 1: one device (`device`);  2..GPX_MAX_GROUP: group; 1 with an explicit \
+                                       transport (not AUTO): a ONE-rank group on devices[0] (the group / RCCL   \
+                                       code path on a single GPU: tests)                                        */
   int32_t devices[GPX_MAX_GROUP];   /* HIP ordinals of the group's ranks                       */
   int32_t transport;                /* GPX_TRANSPORT_*                                         */
-  int32_t refine;                   /* GPX_MIXED: refinement iterations (0 = default 3)        */
+  int32_t refine;                   /* GPX_MIXED: 0 = refine until the relative residual is <= 1e-10 or stops  \
+                                       contracting (at most 12 iterations); > 0 = exactly that many      */
   int32_t reserved[2];
 } gpx_config;
 
@@ -98,6 +103,7 @@ typedef struct gpx_timings {
   double grad_trtri, grad_trace, grad_total; /* gpx_lml_grad: L^-T build, fused K^-1 trace pass, whole call */
   double refine;                           /* GPX_MIXED: ms spent refining alpha in fp64 */
   double refine_resid0, refine_resid;      /* ||y - K alpha|| / ||y|| before / after the refinement */
+  double refine_iters;                     /* GPX_MIXED: refinement iterations the last fit ran */
 } gpx_timings;
 
 /* ---- lifecycle ------------------------------------------------------------- */

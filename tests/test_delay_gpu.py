@@ -38,6 +38,7 @@ def run(N, M, kw, grad):
     (2600, 200, {"devices": 4, "oversubscribe": True}, True, True),     # device group, replicated factor + sharded gradient
     (9000, 300, {"devices": 2, "oversubscribe": True}, False, False),   # device group, library-chosen 1024-blocks
     (9000, 300, {"device": 0, "world": 1, "rank": 0, "comm": "rccl"}, False, False),   # RCCL calls on two streams
+    (9000, 300, {"devices": [0], "transport": "rccl"}, False, False),   # the same through ncclCommInitAll (one-rank group)
 ])
 def test_results_do_not_depend_on_stream_timing(monkeypatch, delay, N, M, kw, grad, small):
     if small:

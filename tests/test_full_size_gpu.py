@@ -1,0 +1,102 @@
+"""GPU: parity AT BASELINE.json's OWN SIZES against committed full-size oracle fixtures.
+
+G5.npz = C3 (configs[2]: N=65536, d=3, RBF l=0.25, fp64, M=4096) and G6.npz = C5 (configs[4]: the same
+with ARD lengthscales (0.3, 0.2, 0.25)) hold what the CPU oracle (oracle/make_golden_full.py: cdist ->
+exp -> level-3 blocked Cholesky -> solve_triangular, 34 GB in place, ~2 minutes on the GPU box's host
+cores) produced: mean[4096], var[4096], logdet, alpha on 1024 fixed rows.  The inputs are regenerated
+from the seed (digests of them are checked).  The reference holds no GP code or vectors,
+so these fixtures pin the HIP path to the build-authored oracle, not to the reference: parity
+"unpinned by the reference", as everywhere in this repo.
+
+Tolerances: fp64 path — north_star's 1e-6 elementwise relative on mean and variance; fp32 path — the
+level the precision study states (profiles/r03_c5_precision_study.json), a study and not a 1e-6 gate
+(SURVEY.md §8d); mixed path — 1e-6 on the MEAN with the default (adaptive) refinement, variance at
+fp32 grade by design (GP docstring).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from gaussianprocesspathmodelling_amd import GP
+from oracle.gp_oracle import synthetic_problem
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    g = dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+    N, d, M = int(g["N"]), int(g["d"]), int(g["M"])
+    X, y, Xs = synthetic_problem(N, d, M, seed=int(g["seed"]))
+    digest = np.array([X.sum(), y.sum(), Xs.sum(), float(X[N // 2, 1]), float(y[N - 1])])
+    assert np.allclose(digest, g["digest"], rtol=1e-13, atol=0), "the generator no longer reproduces the fixture's inputs"
+    ls = g["lengthscale"]
+    g["ls"] = float(ls[0]) if ls.size == 1 else tuple(float(v) for v in ls)
+    return g, X, y, Xs
+
+
+@pytest.fixture(scope="module")
+def c3():
+    return load("G5.npz")
+
+
+@pytest.fixture(scope="module")
+def c5():
+    return load("G6.npz")
+
+
+def errors(gp, mean, var, g):
+    sf2 = float(g["sf2"])
+    mean, var = np.asarray(mean, np.float64), np.asarray(var, np.float64)
+    rm = np.abs(mean - g["mean"]) / np.maximum(np.abs(g["mean"]), 1e-6)
+    rv = np.abs(var - g["var"]) / np.maximum(g["var"], 1e-6 * sf2)
+    a = np.asarray(gp.alpha_, np.float64)[g["alpha_rows"]]
+    return {"mean_rel_max": float(rm.max()), "mean_rel_median": float(np.median(rm)),
+            "mean_abs_max": float(np.abs(mean - g["mean"]).max()),
+            "var_rel_max": float(rv.max()), "var_rel_median": float(np.median(rv)),
+            "var_abs_max": float(np.abs(var - g["var"]).max()),
+            "alpha_err_over_max": float(np.abs(a - g["alpha_sel"]).max() / float(g["alpha_absmax"])),
+            "logdet_rel": abs(gp.log_det_ - float(g["logdet"])) / abs(float(g["logdet"]))}
+
+
+def run(g, X, y, Xs, **kw):
+    with GP(str(g["kernel"]), g["ls"], float(g["sf2"]), float(g["sn2"]), jitter=0.0, **kw) as gp:
+        mean, var = gp.fit(X, y).predict(Xs)
+        assert gp.info_ == 0
+        e = errors(gp, mean, var, g)
+        e["timings"] = gp.timings_
+    print({k: (f"{v:.2e}" if isinstance(v, float) else "") for k, v in e.items() if k != "timings"})
+    return e
+
+
+def fp64_bar(e):
+    assert e["mean_rel_max"] <= 1e-6 and e["var_rel_max"] <= 1e-6      # north_star's criterion
+    assert e["alpha_err_over_max"] <= 1e-8 and e["logdet_rel"] <= 1e-12
+
+
+def test_c3_fp64_matches_the_full_size_oracle(c3):
+    fp64_bar(run(*c3))
+
+
+def test_c5_fp64_ard_matches_the_full_size_oracle(c5):
+    fp64_bar(run(*c5))
+
+
+def test_c5_fp32_stays_at_the_level_the_study_states(c5):
+    e = run(*c5, dtype="float32")
+    # profiles/r03_c5_precision_study.json (N=65536): mean median rel 7e-4 / max abs 3e-3, variance max
+    # abs 5e-6 (median 6.5 % of a variance of ~7e-5), alpha 8e-3 of max|alpha|, log-det 3e-5: bounds = x5
+    assert e["mean_rel_median"] <= 4e-3 and e["mean_abs_max"] <= 1.5e-2
+    assert e["var_abs_max"] <= 2.5e-5
+    assert e["alpha_err_over_max"] <= 4e-2 and e["logdet_rel"] <= 2e-4
+
+
+def test_c5_mixed_default_refinement_gives_an_fp64_grade_mean(c5):
+    e = run(*c5, dtype="mixed")
+    tm = e["timings"]
+    assert e["mean_rel_max"] <= 1e-6                                    # north_star's bar, on the mean
+    assert e["alpha_err_over_max"] <= 1e-8
+    assert 1 <= tm["refine_iters"] <= 12 and tm["refine_resid"] <= 2e-10
+    # the variance is NOT refined: fp32 grade by design and documented as such (GP docstring, gpx.h)
+    assert e["var_abs_max"] <= 2.5e-5

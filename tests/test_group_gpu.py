@@ -154,6 +154,33 @@ def test_devices_list_and_single_entry():
         GP(devices=[0, 63])
 
 
+@pytest.mark.parametrize("transport", ["rccl", "local"])
+def test_one_rank_group_runs_the_group_code_path(monkeypatch, transport):
+    """devices=[0] with an EXPLICIT transport is a one-rank GROUP, not the plain handle: gpx_create ->
+    create_group -> ncclCommInitAll (rccl) / LocalComm (local) -> run_group -> the sharded schedule,
+    whose look-ahead stream issues collectives beside the main stream's update (N = 9000 with the
+    library's 1024-blocks: 9 panels).  The only way a one-GPU box executes ncclCommInitAll and the
+    group's RCCL plumbing at all (more than one rank needs distinct devices: tests/test_multi_gpu.py)."""
+    monkeypatch.delenv("GPX_NB_SHARD", raising=False)
+    X, y, Xs = synthetic_problem(9000, 3, 200, seed=5)
+    ref = OracleGP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    for repl in ("0", "1"):
+        monkeypatch.setenv("GPX_SHARD_REPLICATE", repl)
+        with GP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0, devices=[0], transport=transport) as gp:
+            assert gp._is_group
+            mean, var = gp.fit(X, y).predict(Xs)
+            check(mean, var, gp.alpha_, gp.log_det_, ref, mr, vr)
+    # the gradient through the group entry point (replicated factor), against the oracle's
+    X, y, _ = synthetic_problem(2500, 3, 1, seed=6)
+    ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
+    g_ref = ref.lml_gradient()
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0, devices=[0], transport=transport) as gp:
+        lml, g = gp.fit(X, y).lml_gradient()
+        assert abs(lml - ref.log_marginal_likelihood()) <= 1e-9 * abs(ref.log_marginal_likelihood())
+        assert np.max(np.abs(g - g_ref)) <= 1e-7 * np.max(np.abs(g_ref))
+
+
 def test_devices_group_device_tensor_inputs_and_multi_output():
     torch = pytest.importorskip("torch")
     X, y, Xs = synthetic_problem(1100, 3, 64, seed=9)

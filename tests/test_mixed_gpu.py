@@ -2,7 +2,10 @@
 on the fp32 MFMA engine, alpha refined in fp64 against the matrix-free fp64 kernel, posterior
 mean in fp64.  The refined mean is pinned against the fp64 oracle at a stated tolerance: 1e-6
 elementwise (north_star's own bar) after 3 iterations on these problems, where the pure-fp32
-path of test_fp32_gpu.py is only good to ~1e-3; the variance keeps fp32 accuracy."""
+path of test_fp32_gpu.py is only good to ~1e-3; the variance keeps fp32 accuracy (by design:
+it is never refined — GP docstring).  The default is ADAPTIVE (refine until the relative residual is
+<= 1e-10 or stops contracting); the same bar at the config's own size (N = 65536, where 3
+iterations are NOT enough) is tests/test_full_size_gpu.py."""
 import numpy as np
 import pytest
 
@@ -36,6 +39,22 @@ def test_refined_mean_meets_the_fp64_bar(N, M, k, kernel, ls, noise):
         assert ev <= 2e-3                                            # variance: fp32 accuracy
         m_only = gp.predict(Xs, return_var=False)
         assert np.array_equal(m_only, mean)
+
+
+def test_default_refinement_is_adaptive_and_meets_the_bar():
+    X, y, Xs = synthetic_problem(4000, 3, 300, seed=11)
+    ref = OracleGP("rbf", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, _ = ref.predict(Xs)
+    with GP("rbf", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0, dtype="mixed") as gp:      # refine=0: adaptive
+        mean, _ = gp.fit(X, y).predict(Xs)
+        tm = gp.timings_
+        em = np.max(np.abs(mean - mr) / np.maximum(np.abs(mr), 1e-6))
+        print(f"adaptive: {tm['refine_iters']:.0f} iterations, residual {tm['refine_resid0']:.1e} -> {tm['refine_resid']:.1e}, mean rel {em:.1e}")
+        assert 1 <= tm["refine_iters"] <= 12 and tm["refine_resid"] <= 1e-10 and em <= 1e-6
+        st = gp.get_state()
+        assert st["refine"] == 0
+    with GP("rbf", 0.25, dtype="mixed", refine=4) as gp:
+        assert GP.from_state(gp.get_state()).refine == 4
 
 
 def test_each_refinement_step_contracts_the_residual():

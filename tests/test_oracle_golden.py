@@ -150,3 +150,26 @@ def test_blocked_cholesky_matches_lapack_and_golden(golden_dir):
     np.testing.assert_allclose(var, g["var"], rtol=1e-8, atol=1e-12)
     with pytest.raises(np.linalg.LinAlgError):
         chol_lower_blocked(np.zeros((8, 8)), 4, 4)
+
+
+@pytest.mark.parametrize("name,ls", [("G5.npz", (0.25,)), ("G6.npz", (0.3, 0.2, 0.25))])
+def test_full_size_fixtures_are_what_the_generator_describes(name, ls):
+    """G5 / G6 (oracle/make_golden_full.py, N = 65536: 34 GB and minutes of CPU, so not recomputed here):
+    the stored digests match the inputs the seed regenerates, the shapes and hyper-parameters are the
+    configs', and the stored posterior is a posterior (0 < var < sf2, alpha rows sorted and unique).
+    The full-size HIP parity against them is tests/test_full_size_gpu.py."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name), allow_pickle=False)
+    N, d, M = int(g["N"]), int(g["d"]), int(g["M"])
+    assert (N, d, M) == (65536, 3, 4096) and str(g["kernel"]) == "rbf"
+    assert tuple(float(v) for v in g["lengthscale"]) == ls and float(g["sf2"]) == 1.5 and float(g["sn2"]) == 1e-2
+    X, y, Xs = synthetic_problem(N, d, M, seed=int(g["seed"]))
+    digest = np.array([X.sum(), y.sum(), Xs.sum(), float(X[N // 2, 1]), float(y[N - 1])])
+    assert np.allclose(digest, g["digest"], rtol=1e-13, atol=0)
+    assert g["mean"].shape == (M,) and g["var"].shape == (M,) and g["alpha_sel"].shape == (1024,)
+    assert np.all(g["var"] > 0) and np.all(g["var"] < 1.5) and np.all(np.isfinite(g["mean"]))
+    rows = g["alpha_rows"]
+    assert np.all(np.diff(rows) > 0) and rows[0] >= 0 and rows[-1] < N
+    assert np.abs(g["alpha_sel"]).max() <= float(g["alpha_absmax"])
+    # a posterior mean of this smooth target stays within the data's range
+    assert np.abs(g["mean"]).max() < np.abs(y).max()
