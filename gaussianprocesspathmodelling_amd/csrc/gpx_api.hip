@@ -251,26 +251,39 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
   // FOR the chain (never the other way round), one event per step: batching the events four steps
   // at a time saved 0.3 ms of chain at N = 8192 but let the inverse lag behind the block's last
   // POTF2, and the panel solve waiting for it lost 0.7 ms.
+  // Round 3: the chain advances 128 columns per step — ONE launch factors the 128 x 128 diagonal tile
+  // (POTF2 of 64, the 64 x 64 block below it, its update, POTF2 of the second 64: potf2_128_kernel),
+  // then one solve of the rows below, one update inside the block and one inverse-extension event
+  // per 128 columns instead of per 64 (GPX_DIAG_STEP=64 selects the old stepping: A/B measurement).
+  const int diag_step = [] {  // read per call (tests switch it)
+    const char* e = getenv("GPX_DIAG_STEP");
+    return (e && atoi(e) == 64) ? 64 : 128;
+  }();
   const int nq = nbp / KB;
-  for (int q = 0; q < nq; ++q) {
+  for (int q = 0; q < nq;) {
+    const int w = (diag_step == 128 && q + 1 < nq) ? 2 : 1;  // 64-blocks factored by this step
     const int64_t oq = o + (int64_t)q * KB;
     T* Aqq = A + oq * ld + oq;
     T* Wq = Winv + (oq / KB) * (KB * KB);
-    launch_potf2_64<T>(Aqq, ld, Wq, gidx0 + oq, info, s);
-    const int64_t rem = o + nbp - (oq + KB);
+    if (w == 2)
+      launch_potf2_128<T>(Aqq, ld, Wq, gidx0 + oq, info, s);
+    else
+      launch_potf2_64<T>(Aqq, ld, Wq, gidx0 + oq, info, s);
+    const int64_t rem = o + nbp - (oq + w * KB);
     if (rem > 0) {
-      T* panel = A + (oq + KB) * ld + oq;
-      launch_trsm_rlt<T>(panel, ld, rem, Aqq, ld, Wq, KB, nullptr, 0, s);
-      launch_gemm_nt<T>(64, A + (oq + KB) * ld + (oq + KB), ld, panel, ld, panel, ld, rem, rem, KB, 1, 0, s);
+      T* panel = A + (oq + w * KB) * ld + oq;
+      launch_trsm_rlt<T>(panel, ld, rem, Aqq, ld, Wq, w * KB, nullptr, 0, s);
+      launch_gemm_nt<T>(64, A + (oq + w * KB) * ld + (oq + w * KB), ld, panel, ld, panel, ld, rem, rem, w * KB, 1, 0, s);
     }
-    if (iw) {  // column block q of the inverse
+    if (iw) {  // column blocks q .. q + w - 1 of the inverse
       hipEvent_t e = next_event(h);
       if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (block inverse)");
       HIPCHK(h, hipEventRecord(e, s));
       HIPCHK(h, hipStreamWaitEvent(iw->aux, e, 0));
-      launch_inv_extend<T>(iw->U, iw->ldu, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), q, q + 1, Wp, iw->nbw,
+      launch_inv_extend<T>(iw->U, iw->ldu, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), q, q + w, Wp, iw->nbw,
                            iw->aux);
     }
+    q += w;
   }
   if (iw) {
     iw->ready = next_event(h);
@@ -318,6 +331,15 @@ int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int
 // panel solve and trailing update without being factorised: with the right-hand sides
 // stored there as rows ("bordered matrix"), they leave the factorisation as
 // z^T = (L^-1 y)^T — the forward substitution costs no serial pass of its own.
+// Round 3 — FUSED trailing update (GPX_FUSED_STRIP=1; the default stays the two-launch form: on the
+// bench both take the same time — the boundary between STRIP and REST costs nothing measurable, the
+// "gaps" of the round-2 trace were the strips' own work — and the fused form must not run under
+// rocprofv3 --pmc, which serialises kernels and would starve the parked stream until its time-out):
+// STRIP and REST are ONE launch (gemm_nt_fused_kernel) with the strip's tiles enumerated first.  Each strip slot bumps a device counter (info[8]) when its tile is released; the look-ahead
+// stream is parked on wait_counter_kernel until the strip of this panel is complete and then runs
+// the next diagonal block and panel solve beside the rest of the same launch.  The bordered rows'
+// update of panel p+1 moves behind the panel solve on the look-ahead stream (it touches no row of
+// the matrix proper), i.e. off the chain and inside the previous update.
 template <typename T>
 int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T* P0, T* P1,
                  int64_t ldp, int* info, int64_t gidx0, bool profile, int64_t nx = 0,
@@ -325,6 +347,33 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
   hipStream_t s0 = h->st, s1 = h->st2;
   T* Pbuf[2] = {P0, P1};
   int rc;
+  const bool fuse_env = [] {  // read per call (tests switch it); default OFF: measured equal, see DESIGN.md §5.2
+    const char* e = getenv("GPX_FUSED_STRIP");
+    return e && atoi(e) != 0;
+  }();
+  unsigned* ctr = reinterpret_cast<unsigned*>(info + 8);  // the info buffer is 64 bytes: [0] pivot, [8] strip counter
+  unsigned target = 0;
+  // is the trailing update of the panel at offset o one fused launch?  (128-tiles for strip and rest)
+  auto is_fused = [&](int64_t o) -> bool {
+    if (!fuse_env || o >= n) return false;
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    const int64_t ntrail = n - (o + nbp);
+    if (ntrail <= 0) return false;
+    const int nbn = (int)std::min<int64_t>(nb, ntrail);
+    const int64_t nrest = ntrail - nbn;
+    if (nrest <= 0 || ntrail % 128 != 0 || nbn % 128 != 0) return false;
+    return gemm_nt_tile(128, nrest, nrest, 1) == 128 && gemm_nt_tile(128, ntrail, nbn, 2) == 128;
+  };
+  // bordered rows [n, n+nx) x trailing columns of the panel at offset o (solved panel in Pc)
+  auto bordered_update = [&](int64_t o, const T* Pc, hipStream_t s) {
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    const int64_t t0 = o + nbp, ntrail = n - t0;
+    if (nx <= 0 || ntrail <= 0) return;
+    launch_gemm_nt<T>(nx % 128 == 0 && ntrail % 128 == 0 ? 128 : 64, A + n * ld + t0, ld, Pc + ntrail * ldp, ldp, Pc,
+                      ldp, nx, ntrail, nbp, 0, 0, s);
+  };
+  const bool any_fused = is_fused(0);
+  if (any_fused) HIPCHK(h, hipMemsetAsync(ctr, 0, sizeof(unsigned), s0));
   // prologue: panel 0 on the main stream
   {
     const int nb0 = (int)std::min<int64_t>(nb, n);
@@ -335,6 +384,13 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     {
       PhaseScope ps(h, &h->tm.chol_trsm, profile);
       if ((rc = panel_solve_enqueue(h, A, ld, 0, nb0, n - nb0, nx, Winv, Pbuf[0], ldp, s0, iw, 0))) return rc;
+    }
+    if (any_fused) {
+      bordered_update(0, Pbuf[0], s0);
+      hipEvent_t e_init = next_event(h);
+      if (!e_init) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+      HIPCHK(h, hipEventRecord(e_init, s0));
+      HIPCHK(h, hipStreamWaitEvent(s1, e_init, 0));  // counter reset + panel 0 before the parked stream's first poll
     }
   }
   int step = 0;
@@ -348,19 +404,41 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     const int nbn = (int)std::min<int64_t>(nb, ntrail);  // width of the next panel
     const int64_t nrest = ntrail - nbn;
     const int tile = (ntrail % 128 == 0 && nbn % 128 == 0) ? 128 : 64;
+    hipEvent_t e_panel = next_event(h);
+    if (!e_panel) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+    if (is_fused(o)) {
+      {  // main stream: the whole trailing update, strip first
+        PhaseScope ps(h, &h->tm.chol_syrk, profile);
+        target += launch_gemm_nt_fused<T>(A + t0 * ld + t0, ld, Pc, ldp, ntrail, nbn, nbp, ctr, s0);
+        h->tm.syrk_flops += (double)ntrail * (double)(ntrail + 1) * (double)nbp;
+        h->tm.syrk_launches += 1;
+      }
+      // look-ahead stream: parked until the strip is released, then diagonal block p+1, panel p+1
+      launch_wait_counter(ctr, target, info, s1);
+      {
+        PhaseScope ps(h, &h->tm.chol_diag, profile, s1);
+        if ((rc = diag_enqueue(h, A, ld, t0, nbn, Winv, info, gidx0, s1, iw))) return rc;
+      }
+      {
+        PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
+        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest, nx, Winv, Pn, ldp, s1, iw, (step + 1) & 1))) return rc;
+      }
+      HIPCHK(h, hipEventRecord(e_panel, s1));
+      if (is_fused(t0)) bordered_update(t0, Pn, s1);  // for update p+1: off the chain, beside the rest of update p
+      HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
+      continue;
+    }
     {  // STRIP: rows [t0, n) x cols [t0, t0+nbn), tiles on/below the diagonal
       PhaseScope ps(h, &h->tm.chol_strip, profile);
       launch_gemm_nt<T>(tile, A + t0 * ld + t0, ld, Pc, ldp, Pc, ldp, ntrail, nbn, nbp, 2, 0, s0);
       // bordered rows [n, n+nx) x all trailing cols: their own small launch, so that the
       // SYRK grids (and their XCD balance) stay exactly those of the plain factorisation
-      if (nx > 0)
-        launch_gemm_nt<T>(nx % 128 == 0 && ntrail % 128 == 0 ? 128 : 64, A + n * ld + t0, ld,
-                          Pc + ntrail * ldp, ldp, Pc, ldp, nx, ntrail, nbp, 0, 0, s0);
+      bordered_update(o, Pc, s0);
     }
     // the two streams touch the same matrix: an event that cannot be created / recorded /
     // waited on must fail the call, never let the streams run unordered
-    hipEvent_t e_strip = next_event(h), e_panel = next_event(h);
-    if (!e_strip || !e_panel) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+    hipEvent_t e_strip = next_event(h);
+    if (!e_strip) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
     HIPCHK(h, hipEventRecord(e_strip, s0));
     HIPCHK(h, hipStreamWaitEvent(s1, e_strip, 0));
     {  // look-ahead stream: factor diagonal block p+1, solve panel p+1
@@ -636,6 +714,8 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   HIPCHK(h, hipGetLastError());
   LAUNCHCHK(h);
   collect_phases(h);
+  if (hinfo < 0)  // wait_counter_kernel gave up: the strip of a fused trailing update never reported
+    return fail(h, GPX_E_HIP, "look-ahead signal timed out (fused trailing update; GPX_FUSED_STRIP=0 selects the two-launch form)");
   *info = (hinfo == INT_MAX) ? 0 : (int64_t)hinfo;
   h->fitted = (*info == 0);
   if (h->fitted) h->nbw = h->nb;
@@ -1384,6 +1464,11 @@ int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info) try {
   TCHK(hipMemcpyAsync(&hinfo, dInfo, sizeof(int), hipMemcpyDeviceToHost, st));
   TCHK(hipStreamSynchronize(st));
   TCHK(hipGetLastError());
+  if (hinfo < 0) {
+    g_create_error = "look-ahead signal timed out (fused trailing update)";
+    rc = GPX_E_HIP;
+    goto done;
+  }
   *info = (hinfo == INT_MAX) ? 0 : hinfo;
 done:
   for (void* p : {(void*)dA, (void*)dW, (void*)dP, (void*)dInfo, (void*)dWb, (void*)dUb})

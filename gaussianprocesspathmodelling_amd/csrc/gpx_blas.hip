@@ -183,6 +183,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #endif
 }
 
+// ---- the whole trailing update of a panel in ONE launch (round 3) ------------------------------
+// C (n x n, lower) -= P P^T with the STRIP — the first ts tile columns, which become the next panel —
+// enumerated FIRST: blocks [0, S) are the strip's rectangular super-tile grid (masked to tj <= ti),
+// blocks [S, gridDim) the triangle beyond it, each part with its own XCD chunking (S is a multiple of
+// 64, so a block's XCD is the same in both numberings).  The hardware dispatches blocks in index
+// order, so the strip retires within the first rounds of slots; every strip slot then bumps *ctr
+// (after a device-scope release of its tile), and the look-ahead stream — parked on
+// wait_counter_kernel — starts the next diagonal block while the same launch carries on with the
+// rest: no kernel boundary, no drain and no refill between "strip" and "rest" (they were two
+// launches with an event between them: ~0.2 ms of every panel).
+template <typename T, int BT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_fused_kernel(T* __restrict__ C, int64_t ldc,
+                                                               const T* __restrict__ P, int64_t ldp, int tiles_m,
+                                                               int tiles_s, int S, int sh, int K,
+                                                               unsigned* __restrict__ ctr) {
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
+  const bool strip = (int)blockIdx.x < S;
+  int ti, tj;
+  bool valid;
+  if (strip) {
+    valid = tile_coords<false>(xcd_chunk_id(blockIdx.x, S), tiles_m, tiles_s, sh, 1, BcMask{0, 1, 0}, ti, tj);
+  } else {
+    const int tr = tiles_m - tiles_s;
+    valid = tile_coords<true>(xcd_chunk_id((int64_t)blockIdx.x - S, (int64_t)gridDim.x - S), tr, tr, 8, 0,
+                              BcMask{0, 1, 0}, ti, tj);
+    ti += tiles_s;
+    tj += tiles_s;
+  }
+  if (valid) {
+    typename Num<T>::v4 acc[BT / 32][BT / 32];
+    zero_acc(acc);
+    gemm_tile_g<T, BT, BT>(P + (int64_t)ti * BT * ldp, ldp, P + (int64_t)tj * BT * ldp, ldp, K, acc, smem);
+    store_tile<T, BT, BT, 0>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
+  }
+  if (strip) {  // release this tile (its atomics have reached memory-side coherence), then count the slot
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(ctr, 1u);
+  }
+}
+
 // ---- C = A * W^T with W lower triangular (an explicit block inverse): panel / block solves -----
 // Tile column tj only needs k < (tj + 1) BT.  One workgroup takes tile columns tj AND tn - 1 - tj of
 // its tile row, so every workgroup walks the same total k ((tn + 1) BT): with one tile per
@@ -633,7 +674,8 @@ __global__ __launch_bounds__(256) void potf2_128_kernel(T* __restrict__ A, int64
   const T zero = (T)0;
   T* A21 = A + (int64_t)64 * lda;
   T* A22 = A21 + 64;
-  // lower 16-tiles of the 64x64 block A22, dealt over the waves: (tr, tc), tc <= tr, index idx -> wave idx & 3
+  // lower 16-tiles (tr, tc), tc <= tr, of the 64x64 block A22 in row-major order idx = tr (tr + 1) / 2 + tc;
+  // wave w holds tiles w, w + 4, w + 8 (< 10) in accumulator layout
   T v11[16], v21[16];
   v4 c22[3];
 #pragma unroll
@@ -646,19 +688,18 @@ __global__ __launch_bounds__(256) void potf2_128_kernel(T* __restrict__ A, int64
     const int e = tid + 256 * u, i = e >> 6, k = e & 63;
     v21[u] = A21[(int64_t)i * lda + k];
   }
-  {
-    int idx = 0, slot = 0;
-    for (int tr = 0; tr < 4; ++tr)
-      for (int tc = 0; tc <= tr; ++tc, ++idx) {
-        if ((idx & 3) != wave) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = tr * 16 + Num<T>::drow(l4, r), col = tc * 16 + l15;
-          const T x = (col <= row) ? A22[(int64_t)row * lda + col] : zero;
-          if (slot == 0) c22[0][r] = x; else if (slot == 1) c22[1][r] = x; else c22[2][r] = x;
-        }
-        ++slot;
+  for (int sl = 0; sl < 3; ++sl) {  // this wave's tiles: idx = wave + 4 sl < 10
+    const int idx = wave + 4 * sl;
+    const int tr = idx >= 6 ? 3 : idx >= 3 ? 2 : idx >= 1 ? 1 : 0, tc = idx - tr * (tr + 1) / 2;
+    c22[sl] = (v4){0, 0, 0, 0};
+    if (idx < 10) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = tr * 16 + Num<T>::drow(l4, r), col = tc * 16 + l15;
+        c22[sl][r] = (col <= row) ? A22[(int64_t)row * lda + col] : zero;
       }
+    }
   }
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
@@ -704,18 +745,19 @@ __global__ __launch_bounds__(256) void potf2_128_kernel(T* __restrict__ A, int64
   __syncthreads();
   {
     // A22 <- A22 - L21 L21^T on the lower 16-tiles; the result becomes the working matrix in V
-    int idx = 0, slot = 0;
-    for (int tr = 0; tr < 4; ++tr)
-      for (int tc = 0; tc <= tr; ++tc, ++idx) {
-        if ((idx & 3) != wave) continue;
-        v4 acc = slot == 0 ? c22[0] : slot == 1 ? c22[1] : c22[2];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+      const int idx = wave + 4 * sl;
+      const int tr = idx >= 6 ? 3 : idx >= 3 ? 2 : idx >= 1 ? 1 : 0, tc = idx - tr * (tr + 1) / 2;
+      if (idx < 10) {
+        v4 acc = c22[sl];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
           acc = Num<T>::mfma(-U[(tr * 16 + l15) * PLD + ks * 4 + l4], U[(tc * 16 + l15) * PLD + ks * 4 + l4], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) V[(tr * 16 + Num<T>::drow(l4, r)) * PLD + tc * 16 + l15] = acc[r];
-        ++slot;
       }
+    }
   }
   __syncthreads();
   potf2_lds<T>(V, U, PB, Tm, Rinv, gidx0 + 64, info);  // V = L22, U = W22
@@ -995,6 +1037,22 @@ void launch_gemm_nt(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const 
   launch_gemm_nt_fixed<T>(gemm_nt_tile(tile, m, n, lower), C, ldc, A, lda, B, ldb, m, n, k, lower, mode, st);
 }
 
+// The fused trailing update (gemm_nt_fused_kernel): C (n x n) -= P P^T, lower part, strip of `ns`
+// columns first; returns the number of strip slots (each adds 1 to *ctr when its tile is released).
+template <typename T>
+unsigned launch_gemm_nt_fused(T* C, int64_t ldc, const T* P, int64_t ldp, int64_t n, int64_t ns, int64_t k,
+                              unsigned* ctr, hipStream_t st) {
+  debug_delay(st);
+  const int64_t tm = n / 128, tsn = ns / 128, tr = tm - tsn;
+  int sh;
+  const int64_t S = rect_grid(tm, tsn, sh);
+  const int64_t ts = (tr + 7) / 8;
+  const int64_t R = ts * (ts - 1) / 2 * 64 + ts * 36;
+  hipLaunchKernelGGL((gemm_nt_fused_kernel<T, 128>), dim3((unsigned)(S + R)), dim3(256), 0, st, C, ldc, P, ldp, (int)tm,
+                     (int)tsn, (int)S, sh, (int)k, ctr);
+  return (unsigned)S;
+}
+
 template <typename T>
 void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
                        int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c, hipStream_t st) {
@@ -1083,6 +1141,8 @@ extern "C" int gpx_debug_read_syrk_clock(long long* out) {
                                   int64_t, int64_t, int, int, hipStream_t);                             \
   template void launch_gemm_nt_fixed<T>(int, T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t, \
                                         int64_t, int64_t, int, int, hipStream_t);                       \
+  template unsigned launch_gemm_nt_fused<T>(T*, int64_t, const T*, int64_t, int64_t, int64_t, int64_t,  \
+                                            unsigned*, hipStream_t);                                    \
   template void launch_gemm_nt_bc<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,        \
                                      int64_t, int64_t, int, int, int, hipStream_t);                     \
   template void launch_gemm_nn<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t, int64_t,  \

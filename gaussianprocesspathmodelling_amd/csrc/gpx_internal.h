@@ -85,6 +85,15 @@ int gemm_nt_tile(int tile, int64_t m, int64_t n, int lower);
 template <typename T>
 void launch_gemm_nt_fixed(int tile, T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb,
                     int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st);
+// The whole trailing update of a panel in one launch: C (n x n, 128-tiles, lower) -= P P^T (P: n x k, ldp)
+// with the first ns columns (the strip that becomes the next panel) enumerated first; every strip slot
+// adds 1 to *ctr once its tile is released at device scope.  Returns the number of strip slots.
+template <typename T>
+unsigned launch_gemm_nt_fused(T* C, int64_t ldc, const T* P, int64_t ldp, int64_t n, int64_t ns, int64_t k,
+                              unsigned* ctr, hipStream_t st);
+// One wave that returns once *ctr >= target (polled at device scope, ~2 us period).  Bounded: after
+// ~15 s it gives up, sets *info = INT_MIN (the caller reports it) and returns — never a hung queue.
+void launch_wait_counter(const unsigned* ctr, unsigned target, int* info, hipStream_t st);
 // Sharded trailing update: C (m local rows x n, 128-tiles) -= A B^T restricted to tiles with
 //   tile_col <= ((tile_row / tpb) * P + c) * tpb + tile_row % tpb   (block-cyclic rows).
 // test hook: random spin kernels in front of launches (gpx_debug_set_delay; gpx_misc.hip)

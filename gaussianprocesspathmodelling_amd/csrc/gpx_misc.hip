@@ -321,6 +321,26 @@ void launch_var_rows(const T* VT, int64_t ld, int64_t m, int64_t ncols, double s
 // demands bit-identical outputs).  Off (seed 0) it is one relaxed atomic load per launch.
 namespace {
 std::atomic<uint64_t> g_delay_state{0};
+// Parks a stream until a device-side counter has reached `target` (gemm_nt_fused_kernel's strip
+// slots).  One wave, lane 0 polls with a device-scope load every ~2 us; every wave reaches the
+// exit: after 2^23 polls (~15 s) it records the failure in *info (INT_MIN: reported by the API call)
+// and returns, and every later wait of the same call returns at once.  The kernel boundary behind it
+// is the acquire for whatever the stream runs next.
+__global__ void wait_counter_kernel(const unsigned* ctr, unsigned target, int* info) {
+  if (threadIdx.x == 0) {
+    unsigned polls = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) break;  // an earlier wait gave up
+      __builtin_amdgcn_s_sleep(64);
+      if (++polls > (1u << 23)) {
+        atomicMin(info, (int)0x80000000);
+        break;
+      }
+    }
+  }
+  __threadfence();
+}
+
 __global__ void spin_kernel(long long cycles) {
   const long long t0 = __builtin_amdgcn_s_memtime();
   while (__builtin_amdgcn_s_memtime() - t0 < cycles) {
@@ -353,6 +373,10 @@ void launch_copy2d(T* dst, int64_t ldd, const T* src, int64_t lds, int64_t rows,
   const int64_t total = rows * (cols * (int64_t)sizeof(T) / 16);
   const int64_t bx = (total + 255) / 256;
   hipLaunchKernelGGL(copy2d_kernel<T>, dim3((unsigned)(bx > 8192 ? 8192 : bx)), dim3(256), 0, st, dst, ldd, src, lds, rows, cols);
+}
+
+void launch_wait_counter(const unsigned* ctr, unsigned target, int* info, hipStream_t st) {
+  hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, st, ctr, target, info);
 }
 
 template <typename T>

@@ -41,6 +41,18 @@ def run(N, M, kw, grad):
     (9000, 300, {"devices": [0], "transport": "rccl"}, False, False),   # the same through ncclCommInitAll (one-rank group)
 ])
 def test_results_do_not_depend_on_stream_timing(monkeypatch, delay, N, M, kw, grad, small):
+    run_delay_case(monkeypatch, delay, N, M, kw, grad, small)
+
+
+def test_fused_trailing_update_does_not_depend_on_stream_timing(monkeypatch, delay):
+    """GPX_FUSED_STRIP=1: the look-ahead stream is released by a device counter the strip's tiles bump
+    from inside the running update (no kernel boundary between producer and consumer): 11 panels,
+    random delays in front of a third of all launches, five seeds, bit-identical."""
+    monkeypatch.setenv("GPX_FUSED_STRIP", "1")
+    run_delay_case(monkeypatch, delay, 12288, 300, {}, False, False)
+
+
+def run_delay_case(monkeypatch, delay, N, M, kw, grad, small):
     if small:
         monkeypatch.setenv("GPX_NB_SHARD", "256")
         monkeypatch.setenv("GPX_NB_PRED", "256")

@@ -22,14 +22,15 @@ def seg(a, b):
     for r in fit[a:b]:
         out.append(f'{short(r["Kernel_Name"])}[q{r["Queue_Id"]}] {(r["s"]-fit[a]["s"])/1e3:7.1f}+{(r["e"]-r["s"])/1e3:5.1f}')
     return out
+SPB = 16 if not any("potf2_128" in r["Kernel_Name"] for r in fit) else 8   # chain steps per 1024-block (64- or 128-wide)
 for blk in (0, 3):
-    print(f"--- diagonal block {blk}, steps 2..5 (us from the step's potf2 start: start+duration) ---")
+    print(f"--- diagonal block {blk}, steps 2..5 of {SPB} (us from the step's potf2 start: start+duration) ---")
     for st in range(2, 6):
-        a, b = pot[blk * 16 + st], pot[blk * 16 + st + 1]
+        a, b = pot[blk * SPB + st], pot[blk * SPB + st + 1]
         print(f"step {st}: {(fit[b]['s'] - fit[a]['s'])/1e3:6.1f} us |", "  ".join(seg(a, b)))
 tot = collections.Counter(); cnt = collections.Counter()
 for i in range(len(pot) - 1):
-    if (i + 1) % 16 == 0: continue
+    if (i + 1) % SPB == 0: continue
     tot["step"] += fit[pot[i + 1]]["s"] - fit[pot[i]]["s"]; cnt["step"] += 1
     tot["potf2"] += fit[pot[i]]["e"] - fit[pot[i]]["s"]
-print("mean step (potf2 start to next potf2 start, inside a block): %.1f us; potf2 itself %.1f us" % (tot["step"] / cnt["step"] / 1e3, tot["potf2"] / cnt["step"] / 1e3))
+print("mean step of %d columns (potf2 start to next potf2 start, inside a block): %.1f us; potf2 itself %.1f us" % (1024 // SPB, tot["step"] / cnt["step"] / 1e3, tot["potf2"] / cnt["step"] / 1e3))
