@@ -1697,9 +1697,7 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs) try {
   double *sink = nullptr, *src = nullptr, *dst = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const int64_t count = (int64_t)1 << 28;  // 2 GiB per buffer
-  // the two streams must not sit a power of two apart (same HBM channel / bank phase for the read
-  // and the write of every lane): skew the destination by an odd number of 256-byte pieces
-  const int64_t skew = 8 * 1024 + 32 * 37;
+  const int64_t skew = 0;  // (round 3: a skewed destination measured slower than an aligned one: tools/copy_bw.hip)
   int iters = 65536;  // ~0.23 s: long enough to be past the clock ramp (a 14 ms loop read 75 TF,
                       // the sustained rate is 77.8); GPX_MICROBENCH_ITERS overrides
   if (const char* e = getenv("GPX_MICROBENCH_ITERS")) {
@@ -1722,13 +1720,13 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs) try {
   TCHK(hipEventSynchronize(e1));
   TCHK(hipEventElapsedTime(&ms, e0, e1));
   *mfma_tflops = (double)blocks * 4 * (double)iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
-  launch_copy(src, dst + skew, count, st);  // warm-up
+  for (int r = 0; r < 4; ++r) launch_copy(src, dst + skew, count, st);  // warm-up
   TCHK(hipEventRecord(e0, st));
-  for (int r = 0; r < 5; ++r) launch_copy(src, dst + skew, count, st);
+  for (int r = 0; r < 20; ++r) launch_copy(src, dst + skew, count, st);
   TCHK(hipEventRecord(e1, st));
   TCHK(hipEventSynchronize(e1));
   TCHK(hipEventElapsedTime(&ms, e0, e1));
-  *copy_gbs = 5.0 * 2.0 * (double)count * 8.0 / (ms * 1e-3) / 1e9;
+  *copy_gbs = 20.0 * 2.0 * (double)count * 8.0 / (ms * 1e-3) / 1e9;
   TCHK(hipGetLastError());
 done:
   if (e0) (void)hipEventDestroy(e0);

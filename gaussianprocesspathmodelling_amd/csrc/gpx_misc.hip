@@ -131,23 +131,17 @@ __global__ __launch_bounds__(256, 2) void mfma_loop_kernel(double* sink, int ite
   if (s == 12345.678) sink[0] = s;  // keep the loop alive
 }
 
-// streaming copy, 16 B per lane, four independent loads in flight per lane before the first store
+// streaming copy: ONE 16-byte element per lane, one pass, as many workgroups as it takes, non-temporal
+// loads and stores — the shape that reaches the ~6.3 TB/s class of MI355X_MICROARCH.md's float4 copy
+// (tools/copy_bw.hip, round 3: 6.3 TB/s plain / 6.6 nt; grid-stride loops with 16 k workgroups stay at
+// 4.6-5.0, four loads in flight per lane at 5.3-5.4).  count2 must be a multiple of 256.
 __global__ __launch_bounds__(256) void copy_kernel(const double2* __restrict__ src,
                                                   double2* __restrict__ dst, int64_t count2) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   typedef double v2 __attribute__((ext_vector_type(2)));
-  const v2* s2 = reinterpret_cast<const v2*>(src);
-  v2* d2 = reinterpret_cast<v2*>(dst);
-  for (; i + 3 * stride < count2; i += 4 * stride) {  // streaming: nothing of either buffer is reused
-    const v2 a = __builtin_nontemporal_load(s2 + i), b = __builtin_nontemporal_load(s2 + i + stride),
-             c = __builtin_nontemporal_load(s2 + i + 2 * stride), d = __builtin_nontemporal_load(s2 + i + 3 * stride);
-    __builtin_nontemporal_store(a, d2 + i);
-    __builtin_nontemporal_store(b, d2 + i + stride);
-    __builtin_nontemporal_store(c, d2 + i + 2 * stride);
-    __builtin_nontemporal_store(d, d2 + i + 3 * stride);
-  }
-  for (; i < count2; i += stride) dst[i] = src[i];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < count2)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const v2*>(src) + i),
+                                reinterpret_cast<v2*>(dst) + i);
 }
 
 __global__ __launch_bounds__(256) void fix_diag_kernel(double* A, int64_t lda, int n, int nvalid,
@@ -412,8 +406,8 @@ void launch_mfma_loop(double* sink, int iters, int blocks, hipStream_t st) {
 }
 
 void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st) {
-  hipLaunchKernelGGL(copy_kernel, dim3(16384), dim3(256), 0, st, reinterpret_cast<const double2*>(src),
-                     reinterpret_cast<double2*>(dst), count / 2);
+  hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((count / 2 + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<const double2*>(src), reinterpret_cast<double2*>(dst), count / 2);
 }
 
 }  // namespace gpx
