@@ -125,6 +125,30 @@ def _preload_torch_hip_runtime():
         return None
 
 
+def prefer_torch_rccl():
+    """One RCCL per process, loaded in torch's own order.  PyTorch-ROCm wheels bundle their own
+    librccl.so (and the runtime libraries it needs) and map them with ``import torch``.  Measured on
+    this image (round 3, tools/rccl_exit_probe.py): a process in which libgpx dlopen()s an RCCL —
+    /opt/rocm's or torch's own file — BEFORE torch is imported aborts at exit ("double free or
+    corruption" / "free(): invalid pointer" in the static destructors); torch first, then libgpx's
+    RCCL use, is clean.  So before libgpx's first RCCL use: import torch if it is installed (it is the
+    declared tensor container of this package anyway) and point GPX_RCCL_PATH at its copy, which
+    libgpx then finds already mapped.  Without torch there is nothing to collide with."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return os.environ.get("GPX_RCCL_PATH")
+    import torch  # noqa: F401  (maps torch's RCCL and its dependencies in torch's own order)
+    if "GPX_RCCL_PATH" not in os.environ:
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+        if os.path.exists(p):
+            os.environ["GPX_RCCL_PATH"] = p
+    return os.environ.get("GPX_RCCL_PATH")
+
+
 def load():
     """dlopen csrc/libgpx.so and attach signatures.  Raises if it is not there."""
     global _lib

@@ -1309,14 +1309,11 @@ int gpx_lml_grad(gpx_handle* h, double* lml, double* grad) try {
   if (h->cfg.dtype != GPX_F64) return fail(h, GPX_E_UNSUPPORTED, "gpx_lml_grad: fp64 handles only");
   if (h->group) return group_lml_grad(h, lml, grad);
   if (h->cfg.world > 1 && !h->comm) return fail(h, GPX_E_ARG, "gpx_lml_grad: sharded handle without a communicator");
-  if (h->comm && !h->repl)
-    return fail(h, GPX_E_UNSUPPORTED,
-                "gpx_lml_grad: a sharded handle needs the replicated factor (the whole L on every rank: "
-                "N^2 within 35 % of the card, or GPX_SHARD_REPLICATE=1); the distributed-solve mode does not invert L");
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->err.clear();
   h->phases.clear();
   h->ev_used = 0;
+  if (h->comm && !h->repl) return shard_lml_grad_dist(h, lml, grad);  // factor only held distributed
   return lml_grad_impl(h, lml, grad);
 }
 GPX_CATCH_ALL

@@ -151,6 +151,12 @@ void launch_set_diag_one(double* A, int64_t lda, int64_t n, hipStream_t st);
 // rank `rank` of P covers every P-th octet of 64-slot groups (P = 1: all of them)
 void launch_kinv_trace(int kernel, const double* ZT, int64_t ld, int64_t npad, int64_t n, const double* Xs, int d,
                        int ard, double sf2, double sn2, double* part, int ntheta, int P, int rank, hipStream_t st);
+// the same for a factor that is only held distributed: ZTc (npad rows x ncols, ldc) = the columns of L^-T
+// that belong to this rank's row blocks of L (height nb, block-cyclic over P ranks, local order); every
+// rank visits every tile and contracts over its own columns: the ranks' partial sums add up
+void launch_kinv_trace_cols(int kernel, const double* ZTc, int64_t ldc, int64_t npad, int64_t n, const double* Xs,
+                            int d, int ard, double sf2, double sn2, double* part, int ntheta, int nb, int P, int rank,
+                            int64_t ncols, hipStream_t st);
 // part[slot][t] = sum over the tile of (sum_c alpha_ic alpha_jc) (dK/dlog theta_t)_ij, alphaT (k x npad, ld)
 void launch_alpha_quad(int kernel, const double* alphaT, int64_t ld, int k, int64_t npad, int64_t n,
                        const double* Xs, int d, int ard, double sf2, double sn2, double* part, int ntheta,

@@ -17,23 +17,10 @@ from . import _abi
 OP_SUM, OP_MIN = 0, 1
 
 
-def _torch_rccl_path():
-    import importlib.util
-    spec = importlib.util.find_spec("torch")
-    if spec and spec.origin:
-        p = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
-        if os.path.exists(p):
-            return p
-    return None
-
-
 def init_rccl(lib, handle, rank, world, group=None):
     """Rank 0 draws the unique id, every rank joins: gpx_comm_unique_id / gpx_comm_init."""
     import torch.distributed as dist
-    if "GPX_RCCL_PATH" not in os.environ:
-        p = _torch_rccl_path()          # same RCCL build torch itself runs on
-        if p:
-            os.environ["GPX_RCCL_PATH"] = p
+    _abi.prefer_torch_rccl()            # same RCCL build torch itself runs on: one RCCL per process
     uid = C.create_string_buffer(128)
     if rank == 0:
         rc = lib.gpx_comm_unique_id(uid)

@@ -106,6 +106,8 @@ class GP:
                              "are two different process models: pick one")
         if self.devices:
             self.device = self.devices[0]
+            if self._is_group and transport != "local":
+                _abi.prefer_torch_rccl()     # the group will load RCCL: torch's copy, after torch (see _abi)
         cfg = _abi.GpxConfig(kernel=_abi.KERNEL_IDS[kernel], dtype=_abi.DTYPE_IDS[dtype],
                              device=self.device, block=self.block, rank=self.rank, world=self.world,
                              flags=_abi.FLAG_PROFILE if profile else 0, ndev=len(self.devices),
@@ -336,9 +338,12 @@ class GP:
         gradient w.r.t. the LOG hyper-parameters, ordered (lengthscale[0..n_ls), variance, noise)
         — R&W eq. 5.9, 1/2 tr((alpha alpha^T - K^-1) dK/dtheta), computed on the GPU by
         ``gpx_lml_grad`` (about two more factorisations' worth of MFMA work: L^-T, then K^-1
-        formed and consumed tile by tile, never stored).  fp64 models; sharded ones (``devices=`` or
-        ``world=``) need the replicated-factor mode, in which L^-T is built in row blocks dealt over
-        the GPUs, all-gathered once, and the trace pass is split over the GPUs as well."""
+        formed and consumed tile by tile, never stored).  fp64 models.  Sharded ones (``devices=`` or
+        ``world=``): with the replicated factor L^-T is built in row blocks dealt over the GPUs,
+        all-gathered once, and the trace pass is split over the GPUs; when the factor is only held
+        distributed (C4-sized problems) L^-T is built distributed, every GPU keeps the columns of its
+        own row blocks and contracts the trace over them — either way every rank returns the same
+        numbers."""
         if not self._fitted:
             raise RuntimeError("lml_gradient() before a successful fit()")
         lml = C.c_double(0.0)
@@ -354,9 +359,8 @@ class GP:
         ``params`` chooses what moves ("lengthscale" moves every ARD entry); the search runs in
         log-space with L-BFGS-B.  ``jac="analytic"`` (default): every evaluation is one ``fit()``
         plus one ``lml_gradient()`` on the GPU, about three factorisations' worth of work whatever
-        the number of parameters.  Models without the analytic gradient (float32 / mixed, sharded
-        with distributed solves) fall back to ``jac="3-point"`` central differences: 2 p extra fits
-        per gradient.
+        the number of parameters.  Models without the analytic gradient (float32 / mixed) fall back
+        to ``jac="3-point"`` central differences: 2 p extra fits per gradient.
         Non-positive-definite trial points count as very bad, they do not raise.  Leaves the
         model fitted at the best point found and returns scipy's result (``.fun`` = minus the
         log marginal likelihood there)."""

@@ -136,9 +136,11 @@ int gpx_get_alpha(gpx_handle* h, void* out /* (N,k) host */);
  * (n_ls as passed to gpx_fit).  Costs about two more factorisations' worth of MFMA work
  * (L^-T, then K^-1 = L^-T L^-1 consumed tile by tile as it is formed) and one extra N x N
  * buffer; K^-1 itself is never stored.  fp64 handles.  Sharded handles and groups: collective
- * (every rank calls it, every rank gets the same numbers); both passes are split over the ranks
- * with one all-gather of L^-T between them; needs the replicated-factor mode (GPX_E_UNSUPPORTED
- * when the factor is only held distributed). */
+ * (every rank calls it, every rank gets the same numbers).  Replicated-factor mode: both passes are
+ * split over the ranks with one all-gather of L^-T between them.  Factor only held distributed
+ * (C4-sized problems): L^-T is built by the distributed forward substitution of the variance path,
+ * each rank keeps the columns that belong to its own row blocks (N^2 / P numbers), contracts the
+ * trace over them, and ntheta numbers are all-reduced (round 3; was GPX_E_UNSUPPORTED). */
 int gpx_lml_grad(gpx_handle* h, double* lml, double* grad);
 int gpx_logdet(gpx_handle* h, double* out);
 /* Frees what only the NEXT predict / gradient call would use (the V^T batch, the L^-T buffer of

@@ -83,22 +83,52 @@ def test_group_lml_gradient_matches_single_gpu_and_oracle(monkeypatch, ndev, ker
         assert np.max(np.abs(grad - grad_o)) <= 1e-7 * np.max(np.abs(grad_o))
 
 
-def test_group_gradient_needs_replicated_factor_and_optimize_falls_back(monkeypatch):
-    monkeypatch.setenv("GPX_NB_SHARD", "128")
+@pytest.mark.parametrize("ndev,kernel,N,nbs,k,batch", [
+    (3, "matern52", 2000, 128, 1, 0), (4, "rbf", 3300, 256, 2, 0), (8, "rbf", 5000, 256, 1, 1024),
+    (2, "rbf", 200, 128, 1, 0),            # two blocks on two ranks
+    (5, "matern52", 300, 128, 1, 0),       # three blocks on five ranks: ranks 3, 4 own no column of L^-T
+])
+def test_group_lml_gradient_with_a_distributed_only_factor(monkeypatch, ndev, kernel, N, nbs, k, batch):
+    """GPX_SHARD_REPLICATE=0 — the C4 mode, where no rank holds L: gpx_lml_grad builds L^-T with the
+    distributed forward substitution of the variance path (per-block broadcasts, row batches that skip
+    their structural zeros), keeps on each rank the COLUMNS that belong to its own row blocks, contracts
+    the K^-1 trace over those columns and all-reduces ntheta numbers (shard_lml_grad_dist).  Against
+    the CPU oracle's analytic gradient (k = 1) and the single-GPU gradient."""
+    monkeypatch.setenv("GPX_NB_SHARD", str(nbs))
     monkeypatch.setenv("GPX_SHARD_REPLICATE", "0")
+    if batch:
+        monkeypatch.setenv("GPX_PRED_BATCH", str(batch))     # several row batches of the identity
+    X, y, _ = synthetic_problem(N, 3, 10, seed=41)
+    if k == 2:
+        y = np.stack([y, np.cos(3.0 * y)], axis=1)
+    ls = (0.3, 0.2, 0.25)
+    with GP(kernel, ls, 1.5, 1e-2, jitter=0.0) as g1:
+        lml1, grad1 = g1.fit(X, y).lml_gradient()
+    with GP(kernel, ls, 1.5, 1e-2, jitter=0.0, devices=ndev, oversubscribe=True) as gp:
+        lml, grad = gp.fit(X, y).lml_gradient()
+        assert abs(lml - lml1) <= 1e-10 * abs(lml1)
+        assert np.max(np.abs(grad - grad1)) <= 1e-9 * np.max(np.abs(grad1))
+        lml2, grad2 = gp.lml_gradient()
+        assert lml2 == lml and np.array_equal(grad2, grad)
+    if k == 1:
+        ref = OracleGP(kernel, ls, 1.5, 1e-2, jitter=0.0).fit(X, y)
+        assert abs(lml - ref.log_marginal_likelihood()) <= 1e-9 * abs(ref.log_marginal_likelihood())
+        g_o = ref.lml_gradient()
+        assert np.max(np.abs(grad - g_o)) <= 1e-7 * np.max(np.abs(g_o))
+
+
+def test_group_optimize_uses_the_analytic_gradient_in_both_solve_modes(monkeypatch):
+    monkeypatch.setenv("GPX_NB_SHARD", "128")
     X, y, _ = synthetic_problem(500, 2, 10, seed=3)
-    with GP("rbf", 0.5, 1.0, 0.1, devices=2, oversubscribe=True) as gp:
-        gp.fit(X, y)
-        with pytest.raises(GpxError, match="replicated factor"):
-            gp.lml_gradient()
-        res = gp.optimize(X, y, maxiter=3)          # central differences instead
-        assert np.isfinite(res.fun)
-    monkeypatch.setenv("GPX_SHARD_REPLICATE", "1")
-    with GP("rbf", 0.5, 1.0, 0.1, devices=2, oversubscribe=True) as gp, GP("rbf", 0.5, 1.0, 0.1) as g1:
-        r2 = gp.optimize(X, y, maxiter=25)          # analytic gradient on the group
+    with GP("rbf", 0.5, 1.0, 0.1) as g1:
         r1 = g1.optimize(X, y, maxiter=25)
-        assert abs(r2.fun - r1.fun) <= 1e-6 * abs(r1.fun)
-        assert np.allclose(gp.lengthscale, g1.lengthscale, rtol=1e-3) and np.isclose(gp.noise, g1.noise, rtol=1e-3)
+        for repl in ("0", "1"):
+            monkeypatch.setenv("GPX_SHARD_REPLICATE", repl)
+            with GP("rbf", 0.5, 1.0, 0.1, devices=2, oversubscribe=True) as gp:
+                r2 = gp.optimize(X, y, maxiter=25)
+                assert r2.nfev <= 2 * r1.nfev + 6          # analytic steps, not 2 p fits per gradient
+                assert abs(r2.fun - r1.fun) <= 1e-6 * abs(r1.fun)
+                assert np.allclose(gp.lengthscale, g1.lengthscale, rtol=1e-3) and np.isclose(gp.noise, g1.noise, rtol=1e-3)
 
 
 @pytest.mark.parametrize("repl", [0, 1])
@@ -154,7 +184,7 @@ def test_devices_list_and_single_entry():
         GP(devices=[0, 63])
 
 
-@pytest.mark.parametrize("transport", ["rccl", "local"])
+@pytest.mark.parametrize("transport", ["rccl", "rccl-grouped-initrank", "local"])
 def test_one_rank_group_runs_the_group_code_path(monkeypatch, transport):
     """devices=[0] with an EXPLICIT transport is a one-rank GROUP, not the plain handle: gpx_create ->
     create_group -> ncclCommInitAll (rccl) / LocalComm (local) -> run_group -> the sharded schedule,
@@ -162,6 +192,9 @@ def test_one_rank_group_runs_the_group_code_path(monkeypatch, transport):
     library's 1024-blocks: 9 panels).  The only way a one-GPU box executes ncclCommInitAll and the
     group's RCCL plumbing at all (more than one rank needs distinct devices: tests/test_multi_gpu.py)."""
     monkeypatch.delenv("GPX_NB_SHARD", raising=False)
+    if transport == "rccl-grouped-initrank":      # the other way to create the group's communicators
+        monkeypatch.setenv("GPX_GROUP_INITALL", "0")
+        transport = "rccl"
     X, y, Xs = synthetic_problem(9000, 3, 200, seed=5)
     ref = OracleGP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
     mr, vr = ref.predict(Xs)

@@ -83,7 +83,7 @@ def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N, repl):
 def test_sharded_lml_gradient_over_host_transport(tmp_path, world, N, nbp):
     """gpx_lml_grad on a row-block shard (one process per rank, host transport): L^-T in row blocks
     dealt over the ranks, all-gather, trace pass split over the ranks — against the CPU oracle's
-    analytic gradient; identical on every rank.  The distributed-solve mode refuses."""
+    analytic gradient; identical on every rank.  Then the same with the factor only held distributed."""
     env = {"SHARD_KERNEL": "matern52", "SHARD_NB": "128", "SHARD_N": str(N), "SHARD_GRAD": "1",
            "GPX_NB_PRED": str(nbp), "GPX_SHARD_REPLICATE": "1"}
     res = run_ranks("gpu", world, tmp_path, env, timeout=600)
@@ -95,9 +95,15 @@ def test_sharded_lml_gradient_over_host_transport(tmp_path, world, N, nbp):
         assert abs(float(r["lml"]) - lml_o) <= 1e-9 * abs(lml_o)
         assert np.max(np.abs(r["grad"] - grad_o)) <= 1e-7 * np.max(np.abs(grad_o))
         assert np.array_equal(r["grad"], res[0]["grad"])
+    # factor ONLY held distributed (the C4 mode): L^-T built distributed, its columns on the owners of the
+    # matching row blocks, the trace contracted over the own columns, ntheta numbers all-reduced
     env["GPX_SHARD_REPLICATE"] = "0"
     res = run_ranks("gpu", world, tmp_path, env, timeout=600)
-    assert all("replicated factor" in str(r["grad_err"]) for r in res)
+    for r in res:
+        assert str(r["grad_err"]) == ""
+        assert abs(float(r["lml"]) - lml_o) <= 1e-9 * abs(lml_o)
+        assert np.max(np.abs(r["grad"] - grad_o)) <= 1e-7 * np.max(np.abs(grad_o))
+        assert np.array_equal(r["grad"], res[0]["grad"])
 
 
 def test_c4_shape_on_one_gpu_world4(tmp_path):
