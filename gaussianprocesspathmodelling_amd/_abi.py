@@ -70,6 +70,7 @@ SIGNATURES = {
     "gpx_logdet": (C.c_int, [_P, _PD]),
     "gpx_release_scratch": (C.c_int, [_P]),
     "gpx_get_timings": (C.c_int, [_P, C.POINTER(GpxTimings)]),
+    "gpx_set_flags": (C.c_int, [_P, C.c_int32]),
     "gpx_comm_unique_id": (C.c_int, [_P]),
     "gpx_comm_init": (C.c_int, [_P, _P]),
     "gpx_comm_init_host": (C.c_int, [_P, C.POINTER(GpxHostComm)]),

@@ -1345,6 +1345,15 @@ int gpx_logdet(gpx_handle* h, double* out) try {
 }
 GPX_CATCH_ALL
 
+int gpx_set_flags(gpx_handle* h, int32_t flags) try {
+  if (!h || (flags & ~GPX_FLAG_PROFILE)) return GPX_E_ARG;
+  h->cfg.flags = flags;
+  if (h->group)
+    for (gpx_handle* m : h->group->members) m->cfg.flags = flags;
+  return GPX_OK;
+}
+GPX_CATCH_ALL
+
 int gpx_get_timings(gpx_handle* h, gpx_timings* out) try {
   if (!h || !out) return GPX_E_ARG;
   *out = h->group ? h->group->members[0]->tm : h->tm;  // a group reports rank 0's clocks

@@ -389,6 +389,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_tall_kernel(
   store_tile<T, 256, 128, MODE, 4>(C + (int64_t)ti * 256 * ldc + (int64_t)tj * 128, ldc, acc);
 }
 
+// ---- experimental (round 3): 128x128 tile, EIGHT waves (4 x 2, each 32 x 64), TWO k-steps per barrier --
+// The "BK = 64" variant of the fp32 engine (DESIGN.md §8.4 of round 2): a stage holds two 128-byte
+// lines per row (2 x 2 x 256 rows x 128 B = 128 KB of LDS), so one workgroup of eight waves per CU
+// (two waves per SIMD as before), half the barriers per flop and one barrier for all eight waves.
+// Same triangular tile map as gemm_nt_kernel<.., 128, true, ..>.  Selected by GPX_SYRK_W8=1 for the
+// trailing update (A/B measurement only; K must be a multiple of 2 BK).
+template <typename T, int MODE>
+__global__ __launch_bounds__(512) void gemm_nt_w8_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A,
+                                                         int64_t lda, const T* __restrict__ B, int64_t ldb,
+                                                         int tiles_m, int tiles_n, int K) {
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 128, 128, 2>::SMEM_ELEMS];
+  const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
+  int ti, tj;
+  if (!tile_coords<true>(lin, tiles_m, tiles_n, 8, 0, BcMask{0, 1, 0}, ti, tj)) return;
+  typename Num<T>::v4 acc[2][4];
+  zero_acc(acc);
+  gemm_tile_g<T, 128, 128, 4, 2>(A + (int64_t)ti * 128 * lda, lda, B + (int64_t)tj * 128 * ldb, ldb, K, acc, smem);
+  store_tile<T, 128, 128, MODE, 4>(C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128, ldc, acc);
+}
+
 // ---- C -= A * B, B stored [k][n]; 64x64 tiles --------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(T* __restrict__ C, int64_t ldc,
@@ -1004,6 +1024,15 @@ void launch_gemm_nt_fixed(int tile, T* C, int64_t ldc, const T* A, int64_t lda, 
     hipLaunchKernelGGL((gemm_nt_tall_kernel<T, 0>), dim3(total), dim3(512), 0, st, C, ldc, A, lda, B, ldb,
                        (int)(m / 256), (int)(n / 128), bc2, (int)k, map);
     return;
+  }
+  if (lower == 1 && mode == 0 && tile == 128 && m == n && k % (2 * Num<T>::BK) == 0) {
+    const char* e = getenv("GPX_SYRK_W8");  // read per call: an A/B switch
+    if (e && atoi(e) != 0) {
+      const int64_t tm = m / 128, ts = (tm + 7) / 8;
+      hipLaunchKernelGGL((gemm_nt_w8_kernel<T, 0>), dim3((unsigned)(ts * (ts - 1) / 2 * 64 + ts * 36)), dim3(512), 0, st, C,
+                         ldc, A, lda, B, ldb, (int)tm, (int)tm, (int)k);
+      return;
+    }
   }
   const BcMask bc{0, 1, 0};
   if (tile == 128)

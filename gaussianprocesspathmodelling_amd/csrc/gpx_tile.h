@@ -59,10 +59,12 @@ __device__ __forceinline__ int swz(int row) {
   return ((t & 3) << 1) | (t >> 2);
 }
 
-template <typename T, int BM, int BN>
+// KSUB k-steps share ONE barrier (KSUB = 2: the "BK = 64" fp32 variant of round 3): a stage then holds
+// KSUB consecutive 128-byte lines per row as KSUB images of the layout below, back to back.
+template <typename T, int BM, int BN, int KSUB = 1>
 struct TileShapeG {
   static constexpr int BK = Num<T>::BK;
-  static constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK;
+  static constexpr int A_STAGE = BM * BK * KSUB, B_STAGE = BN * BK * KSUB;
   static constexpr int SMEM_ELEMS = 2 * (A_STAGE + B_STAGE);
 };
 
@@ -71,10 +73,10 @@ struct TileShapeG {
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 // WVM = waves along M (2: 256-thread workgroup, 2 x 2 waves; 4: 512 threads, 4 x 2 waves).
-template <typename T, int BM, int BN, int WVM = 2>
+template <typename T, int BM, int BN, int WVM = 2, int KSUB = 1>
 __device__ __forceinline__ void gemm_tile_g(const T* A, int64_t lda, const T* B, int64_t ldb, int K,
                                             typename Num<T>::v4 (&acc)[BM / (16 * WVM)][BN / 32], T* smem) {
-  using S = TileShapeG<T, BM, BN>;
+  using S = TileShapeG<T, BM, BN, KSUB>;
   using slot_t = typename Num<T>::slot;
   constexpr int BK = S::BK, SL = Num<T>::SLOT;
   constexpr int MT = BM / (16 * WVM), NT = BN / 32, WM = BM / WVM, WN = BN / 2;
@@ -113,9 +115,12 @@ __device__ __forceinline__ void gemm_tile_g(const T* A, int64_t lda, const T* B,
   const int b_off1 = (wc * WN + l15) * BK + ((2 * l4 + 1) ^ sw) * SL;
 
 #pragma unroll
-  for (int q = 0; q < IA; ++q) GPX_GLDS16(ga[q], la + q * RQ);
+  for (int u = 0; u < KSUB; ++u) {
 #pragma unroll
-  for (int q = 0; q < IB; ++q) GPX_GLDS16(gb[q], lb + q * RQ);
+    for (int q = 0; q < IA; ++q) GPX_GLDS16(ga[q] + u * BK, la + u * BM * BK + q * RQ);
+#pragma unroll
+    for (int q = 0; q < IB; ++q) GPX_GLDS16(gb[q] + u * BK, lb + u * BN * BK + q * RQ);
+  }
   __syncthreads();
 
   // Per k-step: 8 first-half fragment reads, then the MFMAs with everything else issued in
@@ -127,52 +132,58 @@ __device__ __forceinline__ void gemm_tile_g(const T* A, int64_t lda, const T* B,
   // to 3.7 %, but nothing covers the tile epilogue and the launch tail any more.)  The DMA is unconditional (clamped to the last step, landing in
   // the buffer nobody reads again) so that the loop body stays one basic block.
   constexpr int HALF = SL * MT * NT;  // MFMAs per half step
-  const int KT = K / BK;
+  const int KT = K / (BK * KSUB);
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
-    const T* Ab = As + buf * S::A_STAGE;
-    const T* Bb = Bs + buf * S::B_STAGE;
-    slot_t a0[MT], b0[NT], a1[MT], b1[NT];
+    const int64_t ko = (int64_t)(kt + 1 < KT ? kt + 1 : kt) * (BK * KSUB);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a0[m] = *reinterpret_cast<const slot_t*>(Ab + a_off0 + m * 16 * BK);
+    for (int u = 0; u < KSUB; ++u) {
+      const T* Ab = As + buf * S::A_STAGE + u * BM * BK;
+      const T* Bb = Bs + buf * S::B_STAGE + u * BN * BK;
+      slot_t a0[MT], b0[NT], a1[MT], b1[NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b0[n] = *reinterpret_cast<const slot_t*>(Bb + b_off0 + n * 16 * BK);
+      for (int m = 0; m < MT; ++m) a0[m] = *reinterpret_cast<const slot_t*>(Ab + a_off0 + m * 16 * BK);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a1[m] = *reinterpret_cast<const slot_t*>(Ab + a_off1 + m * 16 * BK);
+      for (int n = 0; n < NT; ++n) b0[n] = *reinterpret_cast<const slot_t*>(Bb + b_off0 + n * 16 * BK);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b1[n] = *reinterpret_cast<const slot_t*>(Bb + b_off1 + n * 16 * BK);
-    {
-      const int64_t ko = (int64_t)(kt + 1 < KT ? kt + 1 : kt) * BK;
+      for (int m = 0; m < MT; ++m) a1[m] = *reinterpret_cast<const slot_t*>(Ab + a_off1 + m * 16 * BK);
 #pragma unroll
-      for (int q = 0; q < IA; ++q) GPX_GLDS16(ga[q] + ko, la + (buf ^ 1) * S::A_STAGE + q * RQ);
+      for (int n = 0; n < NT; ++n) b1[n] = *reinterpret_cast<const slot_t*>(Bb + b_off1 + n * 16 * BK);
+      {
 #pragma unroll
-      for (int q = 0; q < IB; ++q) GPX_GLDS16(gb[q] + ko, lb + (buf ^ 1) * S::B_STAGE + q * RQ);
-    }
+        for (int q = 0; q < IA; ++q)
+          GPX_GLDS16(ga[q] + ko + u * BK, la + (buf ^ 1) * S::A_STAGE + u * BM * BK + q * RQ);
 #pragma unroll
-    for (int s = 0; s < SL; ++s)
+        for (int q = 0; q < IB; ++q)
+          GPX_GLDS16(gb[q] + ko + u * BK, lb + (buf ^ 1) * S::B_STAGE + u * BN * BK + q * RQ);
+      }
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int s = 0; s < SL; ++s)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = Num<T>::mfma(a0[m][s], b0[n][s], acc[m][n]);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int s = 0; s < SL; ++s)
+          for (int n = 0; n < NT; ++n) acc[m][n] = Num<T>::mfma(a0[m][s], b0[n][s], acc[m][n]);
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int s = 0; s < SL; ++s)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = Num<T>::mfma(a1[m][s], b1[n][s], acc[m][n]);
-    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // first-half fragments first
-    // first quarter of the burst: one second-half fragment read per 2 MFMAs; second
-    // quarter: the DMA of step t+1, one per 2 MFMAs; the second half is pure MFMA (covers
-    // the DMA latency together with the co-resident workgroup's burst)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int i = 0; i < MT + NT; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x8, HALF / (2 * (MT + NT)), 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
+          for (int n = 0; n < NT; ++n) acc[m][n] = Num<T>::mfma(a1[m][s], b1[n][s], acc[m][n]);
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // first-half fragments first
+      // first quarter of the burst: one second-half fragment read per 2 MFMAs; second
+      // quarter: the DMA of step t+1, one per 2 MFMAs; the second half is pure MFMA (covers
+      // the DMA latency together with the co-resident workgroup's burst)
 #pragma unroll
-    for (int i = 0; i < IA + IB; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x8, HALF / (2 * (IA + IB)), 0);
-      __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+      for (int i = 0; i < MT + NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, HALF / (2 * (MT + NT)), 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < IA + IB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, HALF / (2 * (IA + IB)), 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+      }
+      if (KSUB > 1) __builtin_amdgcn_sched_group_barrier(0x8, HALF, 0);  // the rest of this sub-step's MFMAs stay here
     }
     // keep the MFMAs ABOVE the barrier: hipcc otherwise sinks them below the vmcnt(0)
     // drain of __syncthreads() and the DMA latency is exposed on every k-step

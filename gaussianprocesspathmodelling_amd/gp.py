@@ -317,6 +317,10 @@ class GP:
             self._alpha = out[:, 0].copy() if self._y1d else out
         return self._alpha
 
+    def set_profile(self, on):
+        """Switch the per-launch timing of the Cholesky sub-phases (``profile=``) on an existing model."""
+        self._check(self._lib.gpx_set_flags(self._h, _abi.FLAG_PROFILE if on else 0))
+
     @property
     def timings_(self):
         t = _abi.GpxTimings()

@@ -150,6 +150,9 @@ int gpx_logdet(gpx_handle* h, double* out);
  * factor and L^-T are 137 GB each). */
 int gpx_release_scratch(gpx_handle* h);
 int gpx_get_timings(gpx_handle* h, gpx_timings* out);
+/* Replaces gpx_config.flags of an existing handle (GPX_FLAG_PROFILE on / off between calls: bench.py
+ * prices the flag on ONE handle, same buffers).  Groups: applied to every member. */
+int gpx_set_flags(gpx_handle* h, int32_t flags);
 
 /* ---- row-block sharding over RCCL ------------------------------ */
 /* Two process models run the same schedule: the single-process device group above

@@ -345,11 +345,12 @@ def test_hyperparameter_optimisation_climbs_the_marginal_likelihood():
 
 
 @pytest.mark.parametrize("env", [{"GPX_FUSED_STRIP": "1"}, {"GPX_DIAG_STEP": "64"},
-                                 {"GPX_FUSED_STRIP": "1", "GPX_DIAG_STEP": "64"}])
+                                 {"GPX_FUSED_STRIP": "1", "GPX_DIAG_STEP": "64"}, {"GPX_SYRK_W8": "1"}])
 def test_schedule_variants_give_the_same_factorisation(monkeypatch, env):
     """Round-3 schedule switches of the blocked Cholesky: the fused trailing update (strip + rest in ONE
     launch, device-counter hand-over to the look-ahead stream: gemm_nt_fused_kernel / wait_counter_kernel)
-    and the 64-wide diagonal stepping (the default steps 128 columns per launch: potf2_128_kernel).
+    the 64-wide diagonal stepping (the default steps 128 columns per launch: potf2_128_kernel), and the
+    experimental eight-wave / two-k-steps-per-barrier trailing update (gemm_nt_w8_kernel, GPX_SYRK_W8=1).
     N = 12288 with 1024-panels: 11 trailing updates, the first 8 of them large enough to fuse.  Against
     the oracle at 1e-6 and against the default schedule: the fused launch does the same arithmetic per
     tile (bit-identical); the diagonal stepping changes the association inside a 128 x 128 tile only."""
@@ -365,7 +366,7 @@ def test_schedule_variants_give_the_same_factorisation(monkeypatch, env):
         mean, var = gp.fit(X, y).predict(Xs)
         assert gp.info_ == 0
         assert_parity(mean, var, mr, vr, 1.5)
-        if "GPX_DIAG_STEP" not in env:
+        if "GPX_DIAG_STEP" not in env:         # same arithmetic per element, other launch / wave geometry
             assert np.array_equal(mean, m0) and np.array_equal(var, v0) and np.array_equal(gp.alpha_, a0)
         else:
             assert np.max(np.abs(mean - m0)) <= 1e-9 * np.abs(m0).max() and abs(gp.log_det_ - ld0) <= 1e-12 * abs(ld0)

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""PREDICTED multi-GPU budget of the sharded fit + predict — a model, not a measurement:
+no run of this library has ever had more than one physical GPU (SCALE_r01/r02: skipped).  Every input
+is a number measured on ONE MI355X (cited) or a stated assumption about xGMI; when a SCALE record
+exists, the per-term deviations point at the cause.
+
+    python tools/scaling_model.py            # prints the markdown tables of DESIGN.md §6
+
+Schedule modelled (csrc/gpx_shard.inc): row blocks of height nb dealt block-cyclically; per panel p
+  main stream      : STRIP(p) -> REST(p)                      (own rows; MFMA-bound)
+  look-ahead stream: after STRIP(p): diagonal block p+1 on its owner -> broadcast [L_pp | inverses | W_p]
+                     -> every rank solves its rows of panel p+1 -> all-gather -> un-permute
+  step time        = STRIP(p) + max(REST(p), chain(p+1))
+"""
+import json
+
+# ---- measured on one MI355X (profiles/) ---------------------------------------------------------
+RATE = {1024: 68.3e12, 512: 63.2e12, 256: 55e12}   # sharded trailing-update kernel, flop/s (one-rank schedule
+                                                    # 68.3 TF at nb=1024, 63.2 at nb=512; 256: assumption)
+RATE_1GPU = 69.0e12                                 # unsharded SYRK under the bench (profiles/r03_start_bench.json: 69.6)
+CHAIN_US_PER_128 = 75.0                             # diagonal chain alone, per 128 columns (profiles/r03_c2_chain_gaps.txt)
+CHAIN_STRETCH = 5.6                                 # the same chain beside a busy trailing update: 214 ms / 64 blocks
+                                                    # (r03 bench chol_diag) against 0.6 ms per block alone
+SOLVE_RATE = 45e12                                  # panel solve as a dense product with W_p (ltri kernel; DESIGN §5.0: 39 -> ~45 TF)
+SOLVE_FLOOR = 0.27e-3                               # one K = 1024 walk of a 128-tile (C2 trace), scales with nb / 1024
+HBM = 3.0e12                                        # un-permute / copy-back rate actually reached by the copy kernels
+PRED_1GPU = {"trsm_rate": 69e12}                    # variance TRSM at M >= 2048 rows (bench: 254 ms for 1.76e13 flop)
+ZSOLVE = 18e-3                                      # z = L^-1 y on the replicated factor
+# ---- assumptions about the fabric (task statement: 7 links x ~153 GB/s per GPU, full mesh) -------------
+LINK = 153e9 * 0.70                                 # sustained per-link payload rate (70 % of peak: assumption)
+LAT = 30e-6                                         # latency of one RCCL collective on the look-ahead stream (assumption)
+
+
+def pick_nb(N, P):
+    nb = 1024
+    while nb > 256 and nb * 16 * P > N:
+        nb //= 2
+    return nb
+
+
+def chain_time(idle_work, busy_for):
+    """idle_work seconds of chain at idle speed, running beside a trailing update that keeps the owner busy
+    for busy_for seconds (progress 1 / CHAIN_STRETCH while busy, 1 afterwards)."""
+    if busy_for * (1.0 / CHAIN_STRETCH) >= idle_work:
+        return idle_work * CHAIN_STRETCH
+    return busy_for + idle_work - busy_for / CHAIN_STRETCH
+
+
+def fit_time(N, P, nb=None):
+    nb = nb or pick_nb(N, P)
+    rate = RATE[nb] if P > 1 else RATE_1GPU
+    nblk = N // nb
+    diag_idle = nb / 128 * CHAIN_US_PER_128 * 1e-6
+    t = diag_idle + SOLVE_FLOOR                      # head: block 0 and panel 0, nothing to hide behind
+    exposed = 0.0
+    first_exposed = None
+    comm_bytes = 0.0
+    for p in range(nblk - 1):
+        n = N - (p + 1) * nb                         # trailing rows
+        strip = 2.0 * (n * nb - nb * (nb - 1) / 2) * nb / P / rate
+        rest_n = n - nb
+        rest = max(0.0, rest_n * (rest_n + 1.0) * nb / P / rate)
+        # chain of panel p+1 (runs beside REST(p))
+        rows = max(0, n - nb)
+        bc_bytes = (2 * nb * nb + 64 * nb) * 8
+        ag_bytes = rows * nb * 8
+        bcast = 0.0 if P == 1 else LAT + bc_bytes / LINK
+        solve = max(SOLVE_FLOOR * nb / 1024, rows / P * nb * nb / SOLVE_RATE)
+        gather = 0.0 if P == 1 else LAT + ag_bytes / P / LINK       # each peer's piece over its own link (full mesh)
+        unperm = 0.0 if P == 1 else 2 * ag_bytes / HBM
+        ch = chain_time(diag_idle, rest) + bcast + solve + gather + unperm
+        comm_bytes += (bc_bytes + ag_bytes) * (P - 1) / P if P > 1 else 0
+        step = strip + max(rest, ch)
+        if ch > rest:
+            exposed += ch - rest
+            if first_exposed is None:
+                first_exposed = p + 1
+        t += step
+    return {"nb": nb, "fit_s": t, "exposed_chain_s": exposed, "first_exposed_panel": first_exposed, "panels": nblk,
+            "recv_GB_per_rank": comm_bytes / 1e9}
+
+
+def predict_time(N, M, P, replicated):
+    if replicated:                                   # rank r: M / P query points against the whole factor
+        rows = max(128, -(-M // P // 128) * 128)
+        eff = min(1.0, (rows / 2048.0) ** 0.5)       # small row counts fill the chip badly (C2: 55 TF at 4096 x 8192)
+        return N * N * rows / (PRED_1GPU["trsm_rate"] * eff) + 1.5e-3 + (0 if P == 1 else LAT)
+    nb = pick_nb(N, P)                               # distributed variance solve: one (M x nb) broadcast per block, hidden
+    rate = RATE[nb]                                  # behind the rest of the previous update when it is long enough
+    t = 0.0
+    for p in range(N // nb):
+        n = N - (p + 1) * nb
+        upd = 2.0 * M * n * nb / P / rate
+        bc = LAT + M * nb * 8 / LINK + SOLVE_FLOOR * nb / 1024
+        t += max(upd, bc)
+    return t
+
+
+def table(N, M, Ps, replicated, label):
+    rows = []
+    base = None
+    for P in Ps:
+        f = fit_time(N, P)
+        pr = predict_time(N, M, P, replicated and P > 1) if P > 1 else predict_time(N, M, 1, True)
+        extra = (ZSOLVE if replicated or P == 1 else 2 * (N // f["nb"]) * (LAT + 35e-6))   # alpha solves (distributed: not overlapped)
+        tot = f["fit_s"] + pr + extra
+        base = base or tot
+        flops = N ** 3 / 3.0 + float(N) * N * M
+        rows.append({"P": P, **f, "predict_s": pr, "solves_s": extra, "total_s": tot, "points_per_s": (N + M) / tot,
+                     "speedup": base / tot, "efficiency": base / tot / P, "frac_peak": flops / tot / (P * 78.6e12)})
+    print(f"\n**{label}** (N = {N}, M = {M})\n")
+    print("| P | nb | fit ms | of which exposed chain ms | chain first exposed at panel | predict ms | solves ms | total ms | points/s | speed-up | efficiency | fraction of P x 78.6 TF | received per rank GB |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for r in rows:
+        several = len(rows) > 1
+        cells = [r["P"], r["nb"], f"{r['fit_s'] * 1e3:.0f}", f"{r['exposed_chain_s'] * 1e3:.0f}",
+                 f"{r['first_exposed_panel']} of {r['panels']}", f"{r['predict_s'] * 1e3:.0f}", f"{r['solves_s'] * 1e3:.0f}",
+                 f"{r['total_s'] * 1e3:.0f}", f"{r['points_per_s']:.0f}", f"{r['speedup']:.2f}" if several else "-",
+                 f"{r['efficiency']:.2f}" if several else "-", f"{r['frac_peak']:.2f}", f"{r['recv_GB_per_rank']:.1f}"]
+        print("| " + " | ".join(str(c) for c in cells) + " |")
+    return rows
+
+
+if __name__ == "__main__":
+    out = {"C3": table(65536, 4096, (1, 2, 4, 8), True, "C3 sharded, replicated factor (the `bench.py --gpus N` path)"),
+           "C4": table(262144, 4096, (8,), False, "C4, distributed solves (550 GB Gram matrix: 8 GPUs only)")}
+    print("\n```json\n" + json.dumps({"inputs": {"rate": {str(k): v for k, v in RATE.items()}, "rate_1gpu": RATE_1GPU,
+                                                  "chain_us_per_128": CHAIN_US_PER_128, "chain_stretch": CHAIN_STRETCH,
+                                                  "solve_rate": SOLVE_RATE, "link_Bps": LINK, "latency_s": LAT}}) + "\n```")
