@@ -561,6 +561,11 @@ def run(args):
             a, b = C.c_double(0), C.c_double(0)
             if _abi.load().gpx_microbench(C.byref(a), C.byref(b)) == 0:
                 out["microbench"] = {"mfma_f64_loop_tflops": a.value, "stream_copy_gbs": b.value}
+                # the kernel build against the ceiling this card reaches on a plain stream copy (one 16-byte
+                # element per lane, non-temporal: the ~6.3 TB/s class of MI355X_MICROARCH.md), beside the 8 TB/s spec
+                out["kbuild"]["frac_of_measured_stream_copy"] = out["kbuild"]["achieved"] / b.value if b.value > 0 else None
+                out["roofline"]["frac_of_measured_mfma_loop"] = (out["roofline"]["achieved"] / a.value
+                                                                 if a.value > 0 and not shard else None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(full_live=args.cpu_baseline_full)
         if world > 1:
