@@ -100,3 +100,14 @@ def test_c5_mixed_default_refinement_gives_an_fp64_grade_mean(c5):
     assert 1 <= tm["refine_iters"] <= 12 and tm["refine_resid"] <= 2e-10
     # the variance is NOT refined: fp32 grade by design and documented as such (GP docstring, gpx.h)
     assert e["var_abs_max"] <= 2.5e-5
+
+
+@pytest.mark.parametrize("ndev,repl", [(4, "0"), (2, "1")])
+def test_c3_sharded_matches_the_full_size_oracle(monkeypatch, c3, ndev, repl):
+    """The SHARDED path at the bench size against the same full-size oracle fixture (oracle parity of the
+    shard existed only at N <= 9000): 4 ranks with distributed solves — the C4 code path: per-panel
+    broadcast / all-gather, distributed alpha and variance solves — and 2 ranks with the replicated
+    factor, ranks sharing the one GPU over the in-process transport (library-chosen 1024-blocks)."""
+    monkeypatch.delenv("GPX_NB_SHARD", raising=False)
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", repl)
+    fp64_bar(run(*c3, devices=ndev, oversubscribe=True))
