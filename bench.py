@@ -62,6 +62,7 @@ sys.path.insert(0, ROOT)
 N_TRAIN, DIM, M_TEST = 65536, 3, 4096
 KERNEL, LENGTHSCALE, SF2, SN2 = "rbf", 0.25, 1.5, 1e-2
 PEAK_FP64_MFMA_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 FLOP/clk (v_mfma_f64_16x16x4: 2048 FLOP / 64 clk) x 2.4 GHz
+PEAK_FP32_MFMA_TFLOPS = 157.3  # v_mfma_f32_16x16x4: 2048 FLOP / 32 clk
 PEAK_HBM_GBS = 8000.0
 
 
@@ -230,7 +231,12 @@ def main():
     ap.add_argument("--heartbeat", default=None, help="(internal) progress file of a supervised sharded child")
     ap.add_argument("--stall-timeout", type=float, default=300.0,
                     help="auto mode: seconds without child progress before the run counts as failed")
-    ap.add_argument("--workload", choices=["C3", "C4"], default="C3")
+    ap.add_argument("--workload", choices=["C2", "C3", "C4", "C5"], default="C3",
+                    help="BASELINE.json configs[1..4]: C2 N=8192; C3 N=65536 (the metric's config, default); C4 N=262144 Matern on "
+                         "8 GPUs; C5 N=65536 with ARD lengthscales in --dtype float32 (default there) or mixed")
+    ap.add_argument("--dtype", choices=["float64", "float32", "mixed"], default=None,
+                    help="arithmetic of the path (default float64; C5: float32).  Not float64 = another metric config: "
+                         "the line says so in dtype / config")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the multi-rank code on one GPU (host collectives)")
     ap.add_argument("--device", type=int, default=None, help="HIP device override (rehearsal)")
@@ -384,6 +390,16 @@ def run(args):
 
     N, M = args.n, args.m
     kernel = KERNEL
+    lengthscale = LENGTHSCALE
+    dtype = args.dtype or ("float32" if args.workload == "C5" else "float64")
+    if args.workload == "C2" and args.n == N_TRAIN:
+        N = 8192
+    if args.workload == "C5":
+        lengthscale = (0.3, 0.2, 0.25)              # ARD
+    if dtype != "float64" and (world > 1 or args.mode in ("shard", "group")):
+        raise SystemExit("--dtype float32 / mixed: unsharded handles only")
+    tdt = torch.float32 if dtype == "float32" else torch.float64
+    peak_mfma = PEAK_FP64_MFMA_TFLOPS if dtype == "float64" else PEAK_FP32_MFMA_TFLOPS   # the factorisation's engine
     if args.workload == "C4":
         if args.n == N_TRAIN:
             N = 262144
@@ -393,18 +409,20 @@ def run(args):
     group = args.mode == "group"     # rank 0 drives all `world` GPUs from this one process; the other ranks only keep time
     shard = args.mode == "shard" or group   # world == 1: the sharded schedule on one rank (its own overhead)
     X, y, Xs = synthetic(N, DIM, M, 12345 + (0 if shard else rank))   # replicas: own draw each
-    Xd, yd, Xsd = (torch.from_numpy(a).to(dev) for a in (X, y, Xs))
+    Xd, yd, Xsd = (torch.from_numpy(a).to(dev, tdt) for a in (X, y, Xs))
+    if dtype == "float32":
+        X, y, Xs = (a.astype("float32") for a in (X, y, Xs))
     if group:
         gp = None
         if rank == 0:
             devs = [args.device] * world if args.device is not None else list(range(world))
-            gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, block=args.block, profile=True, devices=devs,
+            gp = GP(kernel, lengthscale, SF2, SN2, jitter=0.0, block=args.block, profile=True, devices=devs,
                     transport="local", oversubscribe=args.device is not None)
     elif shard:
-        gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True,
+        gp = GP(kernel, lengthscale, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True,
                 world=world, rank=rank, comm="rccl" if args.backend == "nccl" else "host")
     else:
-        gp = GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True)
+        gp = GP(kernel, lengthscale, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True, dtype=dtype)
     beat(args, "communicator + inputs")
     inject = os.environ.get("GPX_BENCH_INJECT", "")     # rehearsal of the failure path: fail:R / hang:R
 
@@ -447,7 +465,7 @@ def run(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if ctrl_nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ok = True if gp is None else bool(torch.isfinite(mean).all().item() and (var > 0).all().item())
+    ok = True if gp is None else bool(torch.isfinite(mean).all().item() and (var > (0 if dtype == "float64" else -1e-4)).all().item())
     pcie_ms = None
     unprofiled_ms = None
     if world == 1 and not shard:
@@ -477,7 +495,7 @@ def run(args):
         # the sharded posterior against the single-GPU path on the same inputs (rank 0's GPU)
         verdict = [None]
         if rank == 0:
-            with GP(kernel, LENGTHSCALE, SF2, SN2, jitter=0.0, device=local, block=args.block) as one:
+            with GP(kernel, lengthscale, SF2, SN2, jitter=0.0, device=local, block=args.block) as one:
                 m1, v1 = one.fit(Xd, yd).predict(Xsd)
             # north_star's elementwise criterion (1e-6) between two different blockings of the
             # same factorisation, plus the error relative to the largest posterior mean
@@ -520,9 +538,11 @@ def run(args):
                         "step (without, with, without, ...), so that buffers and clock drift are the same"},
             "higher_is_better": True,
             "scaling": "strong" if shard else "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: exact GP fit+predict, N={N} d={DIM} {kernel} fp64, "
-                                   f"M={M}, inputs resident in HBM", "N": N, "d": DIM, "M": M,
+            "vs_baseline": None, "dtype": {"float64": "f64", "float32": "f32", "mixed": "f32 factor + f64 refinement"}[dtype],
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: exact GP fit+predict, N={N} d={DIM} {kernel} "
+                                   f"{'ARD ' if args.workload == 'C5' else ''}{dtype}, M={M}, inputs resident in HBM",
+                       "N": N, "d": DIM, "M": M, "lengthscale": lengthscale,
                        "kernel": kernel, "block": args.block or (shard_block(N, world) if shard else 1024),
                        "parallelism": "1 gpu" if world == 1 else
                        (f"row-block-cyclic shard over {world} gpus (one process, in-process peer-copy transport)" if group else
@@ -539,9 +559,10 @@ def run(args):
             "phases_ms": phases,
             "roofline": {
                 "kernel": "gemm_nt_kernel<128,LOWER> (trailing SYRK of the blocked Cholesky)",
-                "bound": "mfma", "achieved": syrk_tflops, "peak": PEAK_FP64_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": syrk_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": pmc_traffic()[0],
-                "traffic_source": pmc_traffic()[1],
+                "bound": "mfma", "achieved": syrk_tflops, "peak": peak_mfma,
+                "unit": "TFLOP/s", "frac": syrk_tflops / peak_mfma,
+                "traffic": pmc_traffic()[0] if dtype == "float64" and N == N_TRAIN else None,
+                "traffic_source": pmc_traffic()[1] if dtype == "float64" and N == N_TRAIN else None,
                 "launches": launches,
                 "flops_per_launch": acc["syrk_flops"] / max(1, launches),
                 "avg_launch_ms": syrk_ms / max(1, launches)},
@@ -565,8 +586,10 @@ def run(args):
                 # element per lane, non-temporal: the ~6.3 TB/s class of MI355X_MICROARCH.md), beside the 8 TB/s spec
                 out["kbuild"]["frac_of_measured_stream_copy"] = out["kbuild"]["achieved"] / b.value if b.value > 0 else None
                 out["roofline"]["frac_of_measured_mfma_loop"] = (out["roofline"]["achieved"] / a.value
-                                                                 if a.value > 0 and not shard else None)
-        if world == 1 and not args.no_cpu_baseline:
+                                                                 if a.value > 0 and not shard and dtype == "float64" else None)
+        if dtype == "mixed":
+            out["refinement"] = {k_: acc[k_] / steps for k_ in ("refine", "refine_iters", "refine_resid0", "refine_resid")}
+        if world == 1 and not args.no_cpu_baseline and args.workload == "C3" and N == N_TRAIN:
             out["cpu_baseline"] = cpu_baseline(full_live=args.cpu_baseline_full)
         if world > 1:
             sync()
