@@ -183,6 +183,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
 #endif
 }
 
+// block id -> tile of the fused launch (also replayed on the host: gpx_debug_tile_map kind 2)
+__host__ __device__ __forceinline__ bool fused_coords(int64_t bid, int64_t grid, int S, int tiles_m, int tiles_s, int sh,
+                                                     int& ti, int& tj) {
+  if (bid < S) return tile_coords<false>(xcd_chunk_id(bid, S), tiles_m, tiles_s, sh, 1, BcMask{0, 1, 0}, ti, tj);
+  const int tr = tiles_m - tiles_s;
+  const bool ok = tile_coords<true>(xcd_chunk_id(bid - S, grid - S), tr, tr, 8, 0, BcMask{0, 1, 0}, ti, tj);
+  ti += tiles_s;
+  tj += tiles_s;
+  return ok;
+}
+
 // ---- the whole trailing update of a panel in ONE launch (round 3) ------------------------------
 // C (n x n, lower) -= P P^T with the STRIP — the first ts tile columns, which become the next panel —
 // enumerated FIRST: blocks [0, S) are the strip's rectangular super-tile grid (masked to tj <= ti),
@@ -201,16 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fused_kernel(T* __restrict__ C
   __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
   const bool strip = (int)blockIdx.x < S;
   int ti, tj;
-  bool valid;
-  if (strip) {
-    valid = tile_coords<false>(xcd_chunk_id(blockIdx.x, S), tiles_m, tiles_s, sh, 1, BcMask{0, 1, 0}, ti, tj);
-  } else {
-    const int tr = tiles_m - tiles_s;
-    valid = tile_coords<true>(xcd_chunk_id((int64_t)blockIdx.x - S, (int64_t)gridDim.x - S), tr, tr, 8, 0,
-                              BcMask{0, 1, 0}, ti, tj);
-    ti += tiles_s;
-    tj += tiles_s;
-  }
+  const bool valid = fused_coords(blockIdx.x, gridDim.x, S, tiles_m, tiles_s, sh, ti, tj);
   if (valid) {
     typename Num<T>::v4 acc[BT / 32][BT / 32];
     zero_acc(acc);
@@ -473,6 +475,19 @@ __device__ __forceinline__ void potf2_lds(T* __restrict__ Wk, T* __restrict__ Wi
   const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const T zero = (T)0, one = (T)1;
+  // the trailing matrix in registers: wave w owns the lower 16-tiles idx = w, w + 4, w + 8 (< 10; row-major
+  // order idx = tr (tr + 1) / 2 + tc) in accumulator layout
+  v4 R[3];
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) {
+    const int idx = wave + 4 * sl;
+    const int tr = idx >= 6 ? 3 : idx >= 3 ? 2 : idx >= 1 ? 1 : 0, tc = idx - tr * (tr + 1) / 2;
+    R[sl] = (v4){0, 0, 0, 0};
+    if (idx < 10) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) R[sl][r] = Wk[(tr * 16 + Num<T>::drow(l4, r)) * PLD + tc * 16 + l15];
+    }
+  }
   for (int j = 0; j < 64; j += PW) {
     // ---- phase A: PW x PW diagonal factor (redundant per thread, right-looking in
     //      registers) + this thread's panel row
@@ -523,7 +538,9 @@ __device__ __forceinline__ void potf2_lds(T* __restrict__ Wk, T* __restrict__ Wi
     }
     __syncthreads();
     GPX_STAMP(2 + 2 * (j / PW));
-    // ---- phase B: commit the panel, rank-PW update of the trailing lower tiles
+    // ---- phase B: commit the panel, rank-PW update of the trailing lower tiles — which live in the
+    //      accumulators R[] (round 3), not in LDS: two MFMAs per tile and a register subtraction; only
+    //      the 8 columns the NEXT step factors are written back to Wk for phase A to read.
     if (tid < 64 && tid >= j) {
       T* row = Wk + tid * PLD + j;
 #pragma unroll
@@ -531,10 +548,11 @@ __device__ __forceinline__ void potf2_lds(T* __restrict__ Wk, T* __restrict__ Wi
     }
     const int jn = j + PW;
     const int t0 = jn >> 4;
-    int idx = 0;
-    for (int tr = t0; tr < 4; ++tr)
-      for (int tc = t0; tc <= tr; ++tc, ++idx) {
-        if ((idx & 3) != wave) continue;
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+      const int idx = wave + 4 * sl;
+      const int tr = idx >= 6 ? 3 : idx >= 3 ? 2 : idx >= 1 ? 1 : 0, tc = idx - tr * (tr + 1) / 2;
+      if (idx < 10 && tc >= t0) {
         const int colg = tc * 16 + l15;
         v4 acc = {0, 0, 0, 0};
 #pragma unroll
@@ -543,12 +561,15 @@ __device__ __forceinline__ void potf2_lds(T* __restrict__ Wk, T* __restrict__ Wi
           const T bv = (colg >= jn) ? PB[colg * PW + 4 * h + l4] : zero;
           acc = Num<T>::mfma(av, bv, acc);
         }
-        if (colg >= jn) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) R[sl][r] -= acc[r];
+        if (tc == t0 && jn < 64 && (l15 >> 3) == ((jn >> 3) & 1)) {  // columns [jn, jn + 8): the next panel
           T* Cp = Wk + (tr * 16) * PLD + colg;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Cp[Num<T>::drow(l4, r) * PLD] -= acc[r];
+          for (int r = 0; r < 4; ++r) Cp[Num<T>::drow(l4, r) * PLD] = R[sl][r];
         }
       }
+    }
     __syncthreads();
     GPX_STAMP(3 + 2 * (j / PW));
   }
@@ -1126,6 +1147,20 @@ int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, i
     for (int64_t b = 0; b < grid; ++b) {
       int ti, tj;
       if (!tile_coords<true>(xcd_chunk_id(b, grid), (int)tm, (int)tm, 8, 0, BcMask{0, 1, 0}, ti, tj)) continue;
+      if (n >= cap) return -1;
+      out[2 * n] = ti;
+      out[2 * n + 1] = tj;
+      ++n;
+    }
+  } else if (kind == 2) {  // fused trailing update: tm tile rows, strip of tn tile columns first
+    if (tn <= 0 || tn >= tm) return -1;
+    int sh;
+    const int64_t S = rect_grid(tm, tn, sh);
+    const int64_t tr = tm - tn, ts = (tr + 7) / 8;
+    const int64_t grid = S + ts * (ts - 1) / 2 * 64 + ts * 36;
+    for (int64_t b = 0; b < grid; ++b) {
+      int ti, tj;
+      if (!fused_coords(b, grid, (int)S, (int)tm, (int)tn, sh, ti, tj)) continue;
       if (n >= cap) return -1;
       out[2 * n] = ti;
       out[2 * n + 1] = tj;

@@ -211,7 +211,8 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs);
 /* host-only replay of the tile maps of the trailing-update kernels (no GPU needed): kind 0 =
  * lower triangle of a tm x tm grid of 128x128 tiles (unsharded SYRK), kind 1 = the
  * block-cyclic staircase of a rank's tm x tn grid (P ranks, tpb tiles per row block, offset
- * c: local tile row ti owns tj <= ((ti/tpb)*P + c)*tpb + ti%tpb).  Writes (ti, tj) int32
+ * c: local tile row ti owns tj <= ((ti/tpb)*P + c)*tpb + ti%tpb), kind 2 = the fused trailing
+ * update (strip of tn tile columns first, then the triangle beyond it; tm x tm lower).  Writes (ti, tj) int32
  * pairs in launch order into out[2*cap]; returns their count through *count.  Test hook:
  * every owned tile must appear exactly once. */
 int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t tpb, int32_t c,

@@ -82,3 +82,18 @@ def test_first_super_tiles_are_compact(gpx):
         logical[lin] = pairs[b]
     first = logical[:64]
     assert len(set(first[:, 0])) == 8 and len(set(first[:, 1])) == 8
+
+
+@pytest.mark.parametrize("tm,ts", [(504, 8), (16, 8), (9, 8), (100, 8), (33, 4), (24, 16), (8, 1), (7, 2), (65, 8)])
+def test_fused_strip_plus_rest_map_is_a_bijection(gpx, tm, ts):
+    """gemm_nt_fused_kernel (round 3): blocks [0, S) are the strip (first ts tile columns, masked to
+    tj <= ti), the rest the triangle beyond it, each part with its own XCD chunking — together the lower
+    triangle of the tm x tm tile grid, every tile once; and the strip's tiles all come before the rest's
+    in launch order (the hardware dispatches in block order: that is what retires the strip first)."""
+    pairs = tile_map(gpx, 2, tm, ts)
+    want = {(i, j) for i in range(tm) for j in range(i + 1)}
+    got = [tuple(p) for p in pairs.tolist()]
+    assert len(got) == len(set(got)) == len(want) and set(got) == want
+    is_strip = [j < ts for _, j in got]
+    nstrip = sum(is_strip)
+    assert all(is_strip[:nstrip]) and not any(is_strip[nstrip:])
