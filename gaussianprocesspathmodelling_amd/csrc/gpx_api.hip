@@ -198,6 +198,10 @@ void collect_phases(gpx_handle* h) {
   h->ev_used = 0;
 }
 
+struct LatencyGuard {  // set_latency_mode(0) on every exit path of a scheduler function
+  ~LatencyGuard() { set_latency_mode(0); }
+};
+
 // ---- blocked right-looking Cholesky, in place on the lower triangle -------------------
 // A [n][ld]; Winv [n/64][64*64]; P = two compact panel buffers [n][ldp]; n multiple of
 // 64 (128 when n > nb).  Two levels: panels of width nb; inside a panel's diagonal block,
@@ -372,6 +376,19 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     launch_gemm_nt<T>(nx % 128 == 0 && ntrail % 128 == 0 ? 128 : 64, A + n * ld + t0, ld, Pc + ntrail * ldp, ldp, Pc,
                       ldp, nx, ntrail, nbp, 0, 0, s);
   };
+  // does a 128-tile trailing update run beside the look-ahead chain of the panel behind offset o?  If not,
+  // the chain's small launches are alone on the GPU and take the latency mode of the 64-tile engine.
+  auto update_is_big = [&](int64_t o) -> bool {
+    if (o >= n) return false;
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    const int64_t ntrail = n - (o + nbp);
+    if (ntrail <= 0) return false;
+    const int nbn = (int)std::min<int64_t>(nb, ntrail);
+    const int64_t nrest = ntrail - nbn;
+    return nrest > 0 && ntrail % 128 == 0 && nbn % 128 == 0 && gemm_nt_tile(128, nrest, nrest, 1) == 128;
+  };
+  LatencyGuard latency_guard;
+  set_latency_mode(1);  // panel 0: nothing runs beside it
   const bool any_fused = is_fused(0);
   if (any_fused) HIPCHK(h, hipMemsetAsync(ctr, 0, sizeof(unsigned), s0));
   // prologue: panel 0 on the main stream
@@ -406,6 +423,7 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     const int tile = (ntrail % 128 == 0 && nbn % 128 == 0) ? 128 : 64;
     hipEvent_t e_panel = next_event(h);
     if (!e_panel) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+    set_latency_mode(update_is_big(o) ? 0 : 1);  // for everything this iteration enqueues (strip, chain, solve, rest)
     if (is_fused(o)) {
       {  // main stream: the whole trailing update, strip first
         PhaseScope ps(h, &h->tm.chol_syrk, profile);
@@ -495,6 +513,8 @@ int solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld
                       const T* Winv, const SolveWork<T>* wb = nullptr) {
   hipStream_t s0 = h->st, s1 = h->st2;
   const int tile = (rows % 128 == 0) ? 128 : 64;
+  LatencyGuard latency_guard;
+  set_latency_mode(1);  // one stream, nothing beside it; below: until a large update runs beside the block solves
   if (rows < 128 || !s1) {
     for (int64_t o = 0; o < n; o += nb) {
       const int nbp = (int)std::min<int64_t>(nb, n - o);
@@ -543,6 +563,7 @@ int solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld
     const int64_t nrest = ntrail - nbn;
     const int tl = (nbn % 128 == 0 && nrest % 128 == 0) ? tile : 64;
     const int cur = step & 1;
+    set_latency_mode(nrest > 0 && gemm_nt_tile(tl, rows, nrest, 0) == 128 ? 0 : 1);  // a 128-tile REST runs beside block p+1's solve
     const T* Ablk = dense ? Ts[cur] : XT + o;  // the solved block o (rows x nbp)
     const int64_t lda = dense ? ldt : ld;
     launch_gemm_nt<T>(tl, XT + t0, ld, Ablk, lda, L + t0 * ld + o, ld, rows, nbn, nbp, 0, 0, s0);  // STRIP

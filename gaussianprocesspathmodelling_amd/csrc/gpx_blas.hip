@@ -131,11 +131,17 @@ __device__ long long gpx_syrk_clock_buf[8];
 #endif
 
 // ---- C op= A * B^T --------------------------------------------------------------
-template <typename T, int BT, bool TRI, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
+// KSUB k-steps per barrier (round 3).  The 64-tile instantiations — what the library launches when a
+// 128-tile grid would not fill the chip: strips, trailing updates and block products of small problems
+// (BASELINE.json configs[1]), every step of the diagonal chain — are LATENCY-bound: a k-step of a 64 x 64
+// tile is 1024 cycles of MFMA per wave against ~4000 cycles until its LDS-DMA lands, so a K = 1024 walk
+// took 64 round trips (110 us).  With KS64 lines per barrier (64 elements of K: 4 lines fp64, 2 fp32) the
+// loads of a super-step are in flight together: 16 round trips.
+template <typename T, int BT, bool TRI, int MODE, int KSUB = 1>
+__global__ __launch_bounds__(256, (BT == 64 && KSUB >= 4) ? 1 : 2) void gemm_nt_kernel(
     T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
     int64_t ldb, int tiles_m, int tiles_n, int sh, int mask_lower, BcMask bc, int K) {
-  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT, KSUB>::SMEM_ELEMS];
 #ifdef GPX_STAMPS
   const long long cE = __builtin_amdgcn_s_memtime();
 #endif
@@ -155,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     r0 = __builtin_amdgcn_s_memrealtime();
   }
 #endif
-  gemm_tile_g<T, BT, BT>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc,
-                         smem);
+  gemm_tile_g<T, BT, BT, 2, KSUB>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc,
+                                  smem);
 #ifdef GPX_STAMPS
   long long cL = 0;
   if (big) {  // every workgroup of the big launches: sums of prologue / loop cycles and count
@@ -231,12 +237,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fused_kernel(T* __restrict__ C
 // its tile row, so every workgroup walks the same total k ((tn + 1) BT): with one tile per
 // workgroup the long columns set the time of every round of slots and the launch ran at 56 % of
 // the engine's rate (39 TF at N = 65536).
-template <typename T, int BT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_ltri_kernel(T* __restrict__ C, int64_t ldc,
+template <typename T, int BT, int KSUB = 1>
+__global__ __launch_bounds__(256, (BT == 64 && KSUB >= 4) ? 1 : 2) void gemm_nt_ltri_kernel(T* __restrict__ C, int64_t ldc,
                                                               const T* __restrict__ A, int64_t lda,
                                                               const T* __restrict__ W, int64_t ldw, int tiles_m,
                                                               int tiles_n, int sh, int K) {
-  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT>::SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT, KSUB>::SMEM_ELEMS];
   const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
   const int half = (tiles_n + 1) >> 1;
   int ti, tp;
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_ltri_kernel(T* __restrict__ C,
     if (pass == 1 && tj == tiles_n - 1 - tp) break;    // odd tile count: the middle column once
     typename Num<T>::v4 acc[BT / 32][BT / 32];
     zero_acc(acc);
-    gemm_tile_g<T, BT, BT>(At, lda, W + (int64_t)tj * BT * ldw, ldw, min(K, (tj + 1) * BT), acc, smem);
+    gemm_tile_g<T, BT, BT, 2, KSUB>(At, lda, W + (int64_t)tj * BT * ldw, ldw, min(K, (tj + 1) * BT), acc, smem);
     store_tile<T, BT, BT, 1>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
   }
 }
@@ -350,12 +356,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(T* __restrict__ 
                                                                const T* __restrict__ A, int64_t lda,
                                                                const T* __restrict__ B, int64_t ldb, int tiles_n,
                                                                int K, int Ks) {
-  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 64, 64>::SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 64, 64, 2>::SMEM_ELEMS];
   const int ti = blockIdx.x / tiles_n, tj = blockIdx.x % tiles_n, sidx = blockIdx.y;
-  const int k0 = sidx * Ks, kn = min(Ks, K - k0);
+  const int k0 = sidx * Ks, kn = min(Ks, K - k0);  // Ks and K are multiples of 64
   typename Num<T>::v4 acc[2][2];
   zero_acc(acc);
-  gemm_tile_g<T, 64, 64>(A + (int64_t)ti * 64 * lda + k0, lda, B + (int64_t)tj * 64 * ldb + k0, ldb, kn, acc, smem);
+  gemm_tile_g<T, 64, 64, 2, 2>(A + (int64_t)ti * 64 * lda + k0, lda, B + (int64_t)tj * 64 * ldb + k0, ldb, kn, acc, smem);
   store_tile<T, 64, 64, 1>(part + sidx * pstride + (int64_t)ti * 64 * ldp + (int64_t)tj * 64, ldp, acc);
 }
 
@@ -845,11 +851,11 @@ __device__ __forceinline__ void store_tile_transposed(T* Wt, int64_t ldw, const 
 // block upper triangular (slab s is zero left of column block s — the inverse being built from
 // the identity), so slab s starts its contraction at column 64 s.  Wt != null: the solved block
 // is also written transposed, Wt[(64 jb + c) * ldw + 64 slab + r] = X[r][64 jb + c].
-template <typename T>
-__global__ __launch_bounds__(256, 2) void trsm_rlt_kernel(T* X, int64_t ldx, const T* L, int64_t ldl,
+template <typename T, int KSUB>
+__global__ __launch_bounds__(256, KSUB >= 4 ? 1 : 2) void trsm_rlt_kernel(T* X, int64_t ldx, const T* L, int64_t ldl,
                                                           const T* Winv, int jb_lo, int jb_hi, T* P, int64_t ldp,
                                                           int tri, T* Wt, int64_t ldw) {
-  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 64, 64>::SMEM_ELEMS];
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 64, 64, KSUB>::SMEM_ELEMS];
   __builtin_amdgcn_s_setprio(2);  // panel solve is on the critical path of the look-ahead
   T* Xs = X + (int64_t)blockIdx.x * 64 * ldx;
   T* Ps = P ? P + (int64_t)blockIdx.x * 64 * ldp : nullptr;
@@ -859,12 +865,12 @@ __global__ __launch_bounds__(256, 2) void trsm_rlt_kernel(T* X, int64_t ldx, con
     T* Xj = Xs + jb * 64;
     if (jb * 64 > k0) {
       zero_acc(acc);
-      gemm_tile_g<T, 64, 64>(Xs + k0, ldx, L + (int64_t)jb * 64 * ldl + k0, ldl, jb * 64 - k0, acc, smem);
+      gemm_tile_g<T, 64, 64, 2, KSUB>(Xs + k0, ldx, L + (int64_t)jb * 64 * ldl + k0, ldl, jb * 64 - k0, acc, smem);
       store_tile<T, 64, 64, 0>(Xj, ldx, acc);
       __syncthreads();
     }
     zero_acc(acc);
-    gemm_tile_g<T, 64, 64>(Xj, ldx, Winv + (int64_t)jb * 4096, 64, 64, acc, smem);
+    gemm_tile_g<T, 64, 64, 2, KSUB>(Xj, ldx, Winv + (int64_t)jb * 4096, 64, 64, acc, smem);
     // gemm_tile ends with a barrier: every read of T is complete
     store_tile<T, 64, 64, 1>(Xj, ldx, acc);
     if (Ps) store_tile<T, 64, 64, 1>(Ps + jb * 64, ldp, acc);
@@ -911,6 +917,10 @@ int64_t rect_grid(int64_t tm, int64_t tn, int& sh) {
 // workgroup fits per CU spreads them out: a lone workgroup runs 1.75x as fast as one of a
 // co-resident pair.  Matters for the panel / block solves and the strips of small
 // problems (BASELINE.json configs[1]); large launches are unaffected.
+// see launch_gemm_nt_t: several k-steps per barrier for 64-tile launches, only when the caller says that
+// nothing large runs beside them (per host thread: a handle is driven by one thread at a time)
+thread_local int g_latency_mode = 0;
+
 inline int cu_count() {
   static const int n = [] {
     int dev = 0, v = 0;
@@ -933,32 +943,62 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
                                     : tm * tn;
   // 160 KB per CU: static staging (64 KB at BT = 128) + this > 80 KB  =>  one workgroup per CU
   const unsigned spread = (BT == 128 && live <= cu_count()) ? 32 * 1024 : 0;
+  // 64-tiles (latency-bound small launches): several k-steps per barrier, as many as the number of live
+  // tiles lets the LDS afford — up to one tile per CU: 4 (fp64; 128 KB, one workgroup per CU anyway), up to
+  // four per CU: 2 (64 KB, two workgroups per CU), beyond that the plain engine at four workgroups per CU,
+  // whose occupancy hides the latency.  k is a multiple of 64 inside the library.
+  // ONLY in latency mode (set_latency_mode: the caller knows that no large update runs beside this launch):
+  // under a 128-tile trailing update a 64-tile workgroup must fit BESIDE the two resident update workgroups
+  // (2 x 64 KB of the CU's 160 KB: 32 KB is all that is left) — with 64 or 128 KB it waits for a CU to drain,
+  // and at N = 65536 the chain's kernels then took 6x as long (measured: 1242 ms of chain instead of 214).
+  int ks = 1;
+  if (BT == 64 && g_latency_mode) {
+    if (live <= 4 * cu_count() && k % (2 * Num<T>::BK) == 0) ks = 2;
+    if (Num<T>::KS64 == 4 && live <= cu_count() && k % (4 * Num<T>::BK) == 0) ks = 4;
+  }
+#define GPX_NT_LAUNCH(TRI_, MODE_, ...)                                                                                        \
+  do {                                                                                                                         \
+    if (ks == 4)                                                                                                               \
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, TRI_, MODE_, (BT == 64 ? 4 : 1)>), grid, block, spread, st, __VA_ARGS__);      \
+    else if (ks == 2)                                                                                                          \
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, TRI_, MODE_, (BT == 64 ? 2 : 1)>), grid, block, spread, st, __VA_ARGS__);      \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, TRI_, MODE_, 1>), grid, block, spread, st, __VA_ARGS__);                       \
+  } while (0)
   if (lower == 1) {  // full lower triangle, triangular super-tile enumeration
     const int64_t ts = (tm + 7) / 8;
     dim3 grid((unsigned)(ts * (ts - 1) / 2 * 64 + ts * 36));  // tile_coords<TRI>: no masked slots
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 0>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+      GPX_NT_LAUNCH(true, 0, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, true, 1>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+      GPX_NT_LAUNCH(true, 1, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
   } else if (lower == 4) {  // C = A W^T, W lower triangular: paired tile columns (mode 1 only)
     int sh;
     dim3 grid((unsigned)rect_grid(tm, (tn + 1) / 2, sh));
-    hipLaunchKernelGGL((gemm_nt_ltri_kernel<T, BT>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, (int)k);
+    if (ks == 4)
+      hipLaunchKernelGGL((gemm_nt_ltri_kernel<T, BT, (BT == 64 ? 4 : 1)>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, (int)k);
+    else if (ks == 2)
+      hipLaunchKernelGGL((gemm_nt_ltri_kernel<T, BT, (BT == 64 ? 2 : 1)>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, (int)k);
+    else
+      hipLaunchKernelGGL((gemm_nt_ltri_kernel<T, BT, 1>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, (int)k);
   } else {  // rectangle; lower == 2: masked to tj <= ti; lower == 3: block-cyclic mask
     int sh;
     dim3 grid((unsigned)rect_grid(tm, tn, sh));
     const int mask = lower == 2 ? 1 : lower == 3 ? 2 : 0;
     if (mode == 0)
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 0>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
+      GPX_NT_LAUNCH(false, 0, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
     else
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, false, 1>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
+      GPX_NT_LAUNCH(false, 1, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
   }
+#undef GPX_NT_LAUNCH
 }
 
 }  // namespace
 
 // A launcher that refuses its operands (the 128-byte row alignment trsm_rlt_kernel depends on)
 // launches nothing and raises this flag; every API entry point turns it into an error return.
+void set_latency_mode(int on) { g_latency_mode = on; }
+
 static std::atomic<int> g_launch_error{0};
 int take_launch_error() { return g_launch_error.exchange(0); }
 
@@ -985,8 +1025,14 @@ void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
     g_launch_error.store(1);  // reported by the API call in flight (take_launch_error)
     return;
   }
-  hipLaunchKernelGGL(trsm_rlt_kernel<T>, dim3((unsigned)(rows / 64)), dim3(256), 0, st, X, ldx, L, ldl,
-                     Winv, 0, nb / 64, P, ldp, 0, (T*)nullptr, (int64_t)0);
+  // few slabs (the diagonal chain, the alpha solves): every product is one latency-bound walk -> KS64 lines
+  // per barrier; many slabs: the plain engine, whose occupancy hides the latency
+  if (g_latency_mode && rows / 64 <= cu_count())
+    hipLaunchKernelGGL((trsm_rlt_kernel<T, Num<T>::KS64>), dim3((unsigned)(rows / 64)), dim3(256), 0, st, X, ldx, L, ldl,
+                       Winv, 0, nb / 64, P, ldp, 0, (T*)nullptr, (int64_t)0);
+  else
+    hipLaunchKernelGGL((trsm_rlt_kernel<T, 1>), dim3((unsigned)(rows / 64)), dim3(256), 0, st, X, ldx, L, ldl,
+                       Winv, 0, nb / 64, P, ldp, 0, (T*)nullptr, (int64_t)0);
 }
 
 template <typename T>
@@ -997,8 +1043,12 @@ void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv
     g_launch_error.store(1);
     return;
   }
-  hipLaunchKernelGGL(trsm_rlt_kernel<T>, dim3((unsigned)q1), dim3(256), 0, st, U, ldu, L, ldl, Winv, q0, q1,
-                     (T*)nullptr, (int64_t)0, 1, W, ldw);
+  if (g_latency_mode)
+    hipLaunchKernelGGL((trsm_rlt_kernel<T, Num<T>::KS64>), dim3((unsigned)q1), dim3(256), 0, st, U, ldu, L, ldl, Winv, q0, q1,
+                       (T*)nullptr, (int64_t)0, 1, W, ldw);
+  else
+    hipLaunchKernelGGL((trsm_rlt_kernel<T, 1>), dim3((unsigned)q1), dim3(256), 0, st, U, ldu, L, ldl, Winv, q0, q1,
+                       (T*)nullptr, (int64_t)0, 1, W, ldw);
 }
 
 template <typename T>

@@ -64,6 +64,11 @@ void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
 template <typename T>
 void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv, int q0, int q1, T* W,
                        int64_t ldw, hipStream_t st);
+// Latency mode of the calling host thread (default off): the 64-tile launches (launch_gemm_nt with an
+// under-filled 128-grid, launch_trsm_rlt / launch_inv_extend with few slabs) then stage several k-steps per
+// barrier — 64 or 128 KB of LDS per workgroup instead of 32 — which shortens every latency-bound K walk
+// when the GPU is otherwise idle and must NOT be used beside a large trailing update (see gpx_blas.hip).
+void set_latency_mode(int on);
 // 1 if a launcher since the last call refused misaligned operands (and launched nothing); clears the flag
 int take_launch_error();
 // X (rows x nb, ldx) <- X * L^-1 (right, lower, no-transpose; descending blocks).

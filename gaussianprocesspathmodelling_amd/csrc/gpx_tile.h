@@ -21,6 +21,7 @@ struct Num<double> {
   typedef double slot __attribute__((ext_vector_type(2)));  // one 16-byte LDS slot
   static constexpr int SLOT = 2;                            // elements per slot
   static constexpr int BK = 16;  // k-step: 8 slots = one 128-B line per row
+  static constexpr int KS64 = 4; // k-steps per barrier of the 64-tile engine: 64 elements of K per barrier
   static __device__ __forceinline__ v4 mfma(double a, double b, v4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
@@ -33,6 +34,7 @@ struct Num<float> {
   typedef float slot __attribute__((ext_vector_type(4)));
   static constexpr int SLOT = 4;
   static constexpr int BK = 32;
+  static constexpr int KS64 = 2;
   static __device__ __forceinline__ v4 mfma(float a, float b, v4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
