@@ -236,12 +236,20 @@ template <typename T>
 int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, int* info, int64_t gidx0,
                  hipStream_t s, InvWork<T>* iw = nullptr) {
   T* Wp = nullptr;
+  // Hand-over to the side stream WITHOUT events on the chain (round 3): POTF2 of step i publishes i + 1 in
+  // info[9] after a device-scope release; the side stream is parked on wait_counter_kernel in front of each
+  // inverse extension.  The extension of column blocks [q, q + w) needs the rows of L of those blocks, which
+  // are complete with the step's POTF2 (their off-diagonal part came from earlier steps' solves).  A hipEvent
+  // per step cost the chain ~7 us of every 70 (record + the gap it opens).
+  unsigned* dflag = reinterpret_cast<unsigned*>(info + 9);
+  unsigned seq = 0;
   if (iw) {
     Wp = iw->W + (o / iw->nbw) * (int64_t)iw->nbw * iw->nbw;
     // the side stream starts behind everything already queued on s: the W block may live in a
     // buffer that earlier work on s (or, through its waits, on other ranks) is still reading
     hipEvent_t e0 = next_event(h);
     if (!e0) return fail(h, GPX_E_HIP, "hipEventCreate failed (block inverse)");
+    HIPCHK(h, hipMemsetAsync(dflag, 0, sizeof(unsigned), s));  // the block's step flag (info[9]); the chain's stream owns it
     HIPCHK(h, hipEventRecord(e0, s));
     HIPCHK(h, hipStreamWaitEvent(iw->aux, e0, 0));
     HIPCHK(h, hipMemsetAsync(iw->U, 0, (size_t)iw->nbw * iw->ldu * sizeof(T), iw->aux));
@@ -269,21 +277,19 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
     const int64_t oq = o + (int64_t)q * KB;
     T* Aqq = A + oq * ld + oq;
     T* Wq = Winv + (oq / KB) * (KB * KB);
+    ++seq;
     if (w == 2)
-      launch_potf2_128<T>(Aqq, ld, Wq, gidx0 + oq, info, s);
+      launch_potf2_128<T>(Aqq, ld, Wq, gidx0 + oq, info, s, iw ? dflag : nullptr, seq);
     else
-      launch_potf2_64<T>(Aqq, ld, Wq, gidx0 + oq, info, s);
+      launch_potf2_64<T>(Aqq, ld, Wq, gidx0 + oq, info, s, iw ? dflag : nullptr, seq);
     const int64_t rem = o + nbp - (oq + w * KB);
     if (rem > 0) {
       T* panel = A + (oq + w * KB) * ld + oq;
       launch_trsm_rlt<T>(panel, ld, rem, Aqq, ld, Wq, w * KB, nullptr, 0, s);
       launch_gemm_nt<T>(64, A + (oq + w * KB) * ld + (oq + w * KB), ld, panel, ld, panel, ld, rem, rem, w * KB, 1, 0, s);
     }
-    if (iw) {  // column blocks q .. q + w - 1 of the inverse
-      hipEvent_t e = next_event(h);
-      if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (block inverse)");
-      HIPCHK(h, hipEventRecord(e, s));
-      HIPCHK(h, hipStreamWaitEvent(iw->aux, e, 0));
+    if (iw) {  // column blocks q .. q + w - 1 of the inverse, behind this step's POTF2
+      launch_wait_counter(dflag, seq, info, iw->aux);
       launch_inv_extend<T>(iw->U, iw->ldu, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), q, q + w, Wp, iw->nbw,
                            iw->aux);
     }

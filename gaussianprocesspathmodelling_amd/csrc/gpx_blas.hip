@@ -652,10 +652,14 @@ __device__ __forceinline__ void potf2_lds(T* __restrict__ Wk, T* __restrict__ Wi
   __syncthreads();
 }
 
+// flag != null: after the last store of L and the inverse, a device-scope release and *flag = flag_val —
+// the side stream that extends the panel's block inverse is parked on wait_counter_kernel(flag, flag_val)
+// instead of a hipEvent recorded on the chain's stream (round 3: ~7 us per step of the serial chain).
 template <typename T>
 __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_t lda,
                                                        T* __restrict__ Winv, int64_t gidx0,
-                                                       int* __restrict__ info) {
+                                                       int* __restrict__ info, unsigned* __restrict__ flag,
+                                                       unsigned flag_val) {
   __shared__ __attribute__((aligned(16))) T Wk[64 * PLD];  // working matrix -> L (lower)
   __shared__ __attribute__((aligned(16))) T Wi[64 * PLD];  // inverse
   __shared__ __attribute__((aligned(16))) T PB[64 * PW];   // current PW-column panel
@@ -691,6 +695,11 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
     Winv[e] = Wi[ii * PLD + k];
   }
   GPX_STAMP(21);
+  if (flag) {
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, flag_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ---- POTF2 of a 128x128 diagonal tile in ONE launch (round 3) ------------------------------------
@@ -707,7 +716,8 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
 template <typename T>
 __global__ __launch_bounds__(256) void potf2_128_kernel(T* __restrict__ A, int64_t lda,
                                                         T* __restrict__ Winv, int64_t gidx0,
-                                                        int* __restrict__ info) {
+                                                        int* __restrict__ info, unsigned* __restrict__ flag,
+                                                        unsigned flag_val) {
   using v4 = typename Num<T>::v4;
   __shared__ __attribute__((aligned(16))) T U[64 * PLD];
   __shared__ __attribute__((aligned(16))) T V[64 * PLD];
@@ -812,6 +822,11 @@ __global__ __launch_bounds__(256) void potf2_128_kernel(T* __restrict__ A, int64
     const int ii = e >> 6, k = e & 63;
     if (k <= ii) A22[(int64_t)ii * lda + k] = V[ii * PLD + k];
     Winv[4096 + e] = U[ii * PLD + k];
+  }
+  if (flag) {  // see potf2_64_kernel
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, flag_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1003,15 +1018,17 @@ static std::atomic<int> g_launch_error{0};
 int take_launch_error() { return g_launch_error.exchange(0); }
 
 template <typename T>
-void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st) {
+void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st, unsigned* flag,
+                     unsigned flag_val) {
   debug_delay(st);
-  hipLaunchKernelGGL(potf2_64_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, Winv, gidx0, info);
+  hipLaunchKernelGGL(potf2_64_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, Winv, gidx0, info, flag, flag_val);
 }
 
 template <typename T>
-void launch_potf2_128(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st) {
+void launch_potf2_128(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st, unsigned* flag,
+                      unsigned flag_val) {
   debug_delay(st);
-  hipLaunchKernelGGL(potf2_128_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, Winv, gidx0, info);
+  hipLaunchKernelGGL(potf2_128_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, Winv, gidx0, info, flag, flag_val);
 }
 
 template <typename T>
@@ -1244,8 +1261,8 @@ extern "C" int gpx_debug_read_syrk_clock(long long* out) {
 #endif
 
 #define GPX_INSTANTIATE_BLAS(T)                                                                         \
-  template void launch_potf2_64<T>(T*, int64_t, T*, int64_t, int*, hipStream_t);                        \
-  template void launch_potf2_128<T>(T*, int64_t, T*, int64_t, int*, hipStream_t);                       \
+  template void launch_potf2_64<T>(T*, int64_t, T*, int64_t, int*, hipStream_t, unsigned*, unsigned);   \
+  template void launch_potf2_128<T>(T*, int64_t, T*, int64_t, int*, hipStream_t, unsigned*, unsigned);  \
   template void launch_trsm_rlt<T>(T*, int64_t, int64_t, const T*, int64_t, const T*, int, T*, int64_t, \
                                    hipStream_t);                                                        \
   template void launch_trsm_rln<T>(T*, int64_t, int64_t, const T*, int64_t, const T*, int, hipStream_t); \

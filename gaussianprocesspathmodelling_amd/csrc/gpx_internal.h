@@ -45,12 +45,16 @@ void launch_kbuild_cross(int kernel, const T* As, int64_t m, int64_t mpad, const
 // In-place Cholesky of one 64x64 diagonal block (lower) + its inverse Winv (64x64,
 // row-major, upper part zero).  gidx0 = global index of the block's first row (info).
 template <typename T>
-void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st);
+void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st, unsigned* flag = nullptr,
+                     unsigned flag_val = 0);
 // The same for a 128x128 diagonal tile in one launch: L11, L21, L22 in place and the TWO 64x64 inverses
 // of its diagonal blocks (Winv[0..4096), Winv[4096..8192)); the 64 x 64 block above the diagonal is
 // not touched.
+// flag != null (both kernels): *flag = flag_val after a device-scope release of the results — what a stream parked
+// on launch_wait_counter(flag, flag_val) waits for.
 template <typename T>
-void launch_potf2_128(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st);
+void launch_potf2_128(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st, unsigned* flag = nullptr,
+                      unsigned flag_val = 0);
 // X (rows x nb, ldx) <- X * L^-T; L (nb x nb, ldl) lower, Winv = nb/64 inverse diag
 // blocks.  rows, nb multiples of 64.  If P != null the result is also written to the
 // compact panel P (rows x nb, ldp).

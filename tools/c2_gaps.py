@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-short = lambda n: ("potf2" if "potf2" in n else "trsm" if "trsm_rlt" in n else "syrk64" if "gemm_nt_kernel<double, 64, true" in n
+short = lambda n: ("potf2" if "potf2" in n else "wait" if "wait_counter" in n else "trsm" if "trsm_rlt" in n else "syrk64" if "gemm_nt_kernel<double, 64, true" in n
                    else "gemm128" if "gemm_nt_kernel<double, 128" in n else "ltri" if "ltri" in n else "gemm64" if "gemm_nt_kernel<double, 64" in n
                    else "kbuild" if "kbuild" in n else "copy" if "copy" in n.lower() else "fill" if "fill" in n else n[:24])
 # last fit = after the last symmetric kbuild
