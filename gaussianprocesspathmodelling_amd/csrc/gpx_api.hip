@@ -241,8 +241,15 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
   // inverse extension.  The extension of column blocks [q, q + w) needs the rows of L of those blocks, which
   // are complete with the step's POTF2 (their off-diagonal part came from earlier steps' solves).  A hipEvent
   // per step cost the chain ~7 us of every 70 (record + the gap it opens).
-  unsigned* dflag = reinterpret_cast<unsigned*>(info + 9);
+  // GPX_CHAIN_FLAG=0 selects the hipEvent per step again: REQUIRED under `rocprofv3 --pmc` (counter collection
+  // serialises kernels across queues in an order of its own; the parked wait kernel then runs before the POTF2 it
+  // waits for and only its time-out ends the stand-off — measured: the bench dies after 15 s).
+  unsigned* dflag = reinterpret_cast<unsigned*>(info + 9);  // `info` is a 64-byte buffer: [0] pivot, [8] strip counter, [9] step flag
   unsigned seq = 0;
+  const bool use_flag = [] {
+    const char* e = getenv("GPX_CHAIN_FLAG");
+    return !(e && atoi(e) == 0);
+  }();
   if (iw) {
     Wp = iw->W + (o / iw->nbw) * (int64_t)iw->nbw * iw->nbw;
     // the side stream starts behind everything already queued on s: the W block may live in a
@@ -279,9 +286,9 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
     T* Wq = Winv + (oq / KB) * (KB * KB);
     ++seq;
     if (w == 2)
-      launch_potf2_128<T>(Aqq, ld, Wq, gidx0 + oq, info, s, iw ? dflag : nullptr, seq);
+      launch_potf2_128<T>(Aqq, ld, Wq, gidx0 + oq, info, s, iw && use_flag ? dflag : nullptr, seq);
     else
-      launch_potf2_64<T>(Aqq, ld, Wq, gidx0 + oq, info, s, iw ? dflag : nullptr, seq);
+      launch_potf2_64<T>(Aqq, ld, Wq, gidx0 + oq, info, s, iw && use_flag ? dflag : nullptr, seq);
     const int64_t rem = o + nbp - (oq + w * KB);
     if (rem > 0) {
       T* panel = A + (oq + w * KB) * ld + oq;
@@ -289,7 +296,14 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
       launch_gemm_nt<T>(64, A + (oq + w * KB) * ld + (oq + w * KB), ld, panel, ld, panel, ld, rem, rem, w * KB, 1, 0, s);
     }
     if (iw) {  // column blocks q .. q + w - 1 of the inverse, behind this step's POTF2
-      launch_wait_counter(dflag, seq, info, iw->aux);
+      if (use_flag) {
+        launch_wait_counter(dflag, seq, info, iw->aux);
+      } else {
+        hipEvent_t e = next_event(h);
+        if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (block inverse)");
+        HIPCHK(h, hipEventRecord(e, s));
+        HIPCHK(h, hipStreamWaitEvent(iw->aux, e, 0));
+      }
       launch_inv_extend<T>(iw->U, iw->ldu, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), q, q + w, Wp, iw->nbw,
                            iw->aux);
     }
@@ -742,7 +756,9 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   LAUNCHCHK(h);
   collect_phases(h);
   if (hinfo < 0)  // wait_counter_kernel gave up: the strip of a fused trailing update never reported
-    return fail(h, GPX_E_HIP, "look-ahead signal timed out (fused trailing update; GPX_FUSED_STRIP=0 selects the two-launch form)");
+    return fail(h, GPX_E_HIP,
+                "a stream parked on a device flag timed out: kernels are being serialised across streams (rocprofv3 --pmc?) — "
+                "set GPX_CHAIN_FLAG=0 (and leave GPX_FUSED_STRIP unset) to hand over by hipEvents instead");
   *info = (hinfo == INT_MAX) ? 0 : (int64_t)hinfo;
   h->fitted = (*info == 0);
   if (h->fitted) h->nbw = h->nb;
@@ -1498,7 +1514,7 @@ int gpx_potrf(double* A, int64_t n, int32_t block, int64_t* info) try {
   TCHK(hipStreamSynchronize(st));
   TCHK(hipGetLastError());
   if (hinfo < 0) {
-    g_create_error = "look-ahead signal timed out (fused trailing update)";
+    g_create_error = "a stream parked on a device flag timed out (kernels serialised across streams? set GPX_CHAIN_FLAG=0)";
     rc = GPX_E_HIP;
     goto done;
   }
