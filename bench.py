@@ -96,7 +96,7 @@ def pmc_traffic():
     fetch = write = None
     with open(files[-1]) as f:
         for row in csv.DictReader(f):
-            if "gemm_nt_kernel<double, 128, true, 0>" in row["Kernel_Name"]:
+            if "gemm_nt_kernel<double, 128, true, 0" in row["Kernel_Name"]:
                 if row["Counter_Name"] == "FETCH_SIZE":
                     fetch = float(row["mean"])
                 elif row["Counter_Name"] == "WRITE_SIZE":

@@ -13,7 +13,7 @@ ke = [i for i, r in enumerate(rows) if "kbuild_kernel<double, 0, false" in r["Ke
 a, b = ks[-2] if len(ks) > 1 else ks[-1], None
 b = [i for i in ke if i > a][0]
 fit = rows[a:b]
-big = [r for r in fit if "gemm_nt_kernel<double, 128, true, 0>" in r["Kernel_Name"] or "gemm_nt_fused_kernel<double" in r["Kernel_Name"]]   # the trailing updates (REST, or the fused strip + rest launch)
+big = [r for r in fit if "gemm_nt_kernel<double, 128, true, 0" in r["Kernel_Name"] or "gemm_nt_fused_kernel<double" in r["Kernel_Name"]]   # the trailing updates (REST, or the fused strip + rest launch)
 print("REST launches found:", len(big), " fit span %.1f ms" % ((fit[-1]["e"] - fit[0]["s"]) / 1e6))
 tot_rest = sum(r["e"] - r["s"] for r in big)
 gaps = [(big[i + 1]["s"] - big[i]["e"]) / 1e3 for i in range(len(big) - 1)]
