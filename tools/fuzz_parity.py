@@ -39,6 +39,10 @@ def one_case(rng, c):
     ref = OracleGP(kernel, ls, sf2, sn2, jitter=0.0).fit(X, y)
     mr, vr = ref.predict(Xs)
     kw = {}
+    # round-3 schedule switches, at random: 64-wide diagonal steps, hipEvent hand-over of the diagonal chain
+    variant = {"GPX_DIAG_STEP": str(rng.choice(["128", "64"])), "GPX_CHAIN_FLAG": str(rng.choice(["1", "0"]))}
+    os.environ.update(variant)
+    tag += f" step={variant['GPX_DIAG_STEP']} flag={variant['GPX_CHAIN_FLAG']}"
     if ndev > 1:
         os.environ["GPX_SHARD_REPLICATE"] = str(repl)
         os.environ["GPX_NB_SHARD"] = str(nbs)
@@ -52,11 +56,13 @@ def one_case(rng, c):
                  "alpha": float(np.max(np.abs(gp.alpha_ - ref.alpha_)) / np.max(np.abs(ref.alpha_))),
                  "logdet": float(abs(gp.log_det_ - ref.log_det_) / abs(ref.log_det_)),
                  "mean_only": float(np.max(np.abs(m2 - mean)) / max(np.max(np.abs(mean)), 1e-30)), "grad": 0.0}
-            if (ndev == 1 or repl == 1) and N <= 1600:
+            if N <= 1600:        # round 3: also when the factor is only held distributed (ndev > 1, repl 0)
                 lml, grad = gp.lml_gradient()
                 go, lo = ref.lml_gradient(), ref.log_marginal_likelihood()
                 e["grad"] = float(max(np.max(np.abs(grad - go)) / np.max(np.abs(go)), abs(lml - lo) / abs(lo)))
     finally:
+        os.environ.pop("GPX_DIAG_STEP", None)
+        os.environ.pop("GPX_CHAIN_FLAG", None)
         os.environ.pop("GPX_SHARD_REPLICATE", None)
         os.environ.pop("GPX_NB_SHARD", None)
     return tag, e
