@@ -468,7 +468,9 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     }
     {  // STRIP: rows [t0, n) x cols [t0, t0+nbn), tiles on/below the diagonal
       PhaseScope ps(h, &h->tm.chol_strip, profile);
+      set_latency_mode(1);  // the strip runs alone (the look-ahead stream waits for it)
       launch_gemm_nt<T>(tile, A + t0 * ld + t0, ld, Pc, ldp, Pc, ldp, ntrail, nbn, nbp, 2, 0, s0);
+      set_latency_mode(update_is_big(o) ? 0 : 1);
       // bordered rows [n, n+nx) x all trailing cols: their own small launch, so that the
       // SYRK grids (and their XCD balance) stay exactly those of the plain factorisation
       bordered_update(o, Pc, s0);
@@ -583,10 +585,11 @@ int solve_fwd_enqueue(gpx_handle* h, T* XT, int64_t rows, const T* L, int64_t ld
     const int64_t nrest = ntrail - nbn;
     const int tl = (nbn % 128 == 0 && nrest % 128 == 0) ? tile : 64;
     const int cur = step & 1;
-    set_latency_mode(nrest > 0 && gemm_nt_tile(tl, rows, nrest, 0) == 128 ? 0 : 1);  // a 128-tile REST runs beside block p+1's solve
     const T* Ablk = dense ? Ts[cur] : XT + o;  // the solved block o (rows x nbp)
     const int64_t lda = dense ? ldt : ld;
+    set_latency_mode(1);  // the STRIP runs alone: the look-ahead stream waits for it, the previous REST is over
     launch_gemm_nt<T>(tl, XT + t0, ld, Ablk, lda, L + t0 * ld + o, ld, rows, nbn, nbp, 0, 0, s0);  // STRIP
+    set_latency_mode(nrest > 0 && gemm_nt_tile(tl, rows, nrest, 0) == 128 ? 0 : 1);  // a 128-tile REST runs beside block p+1's solve
     hipEvent_t e_strip = next_event(h), e_panel = next_event(h);
     if (!e_strip || !e_panel) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
     HIPCHK(h, hipEventRecord(e_strip, s0));
