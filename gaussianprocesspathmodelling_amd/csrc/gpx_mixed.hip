@@ -16,18 +16,46 @@ constexpr double SQRT5 = 2.23606797749978969640917366873128;
 constexpr int XMAXD = 32;
 constexpr int KMAX = 8;  // target columns of the mixed mode
 
+// exp(x) for x <= 0, branch-free: Cody-Waite reduction x = n ln2 + r, |r| <= ln2 / 2, degree-13 Taylor
+// polynomial of exp(r) (truncation 0.347^14 / 14! = 4e-18: below an ulp), v_ldexp for 2^n (underflows to 0
+// by itself).  ~20 fp64 instructions against the library exp with its special cases; the matrix-free
+// products of the mixed mode regenerate N^2 kernel values per pass.  Measured (round 3, N = 65536, six
+// refinement iterations): 193 -> 178 ms — the pass is a smaller part of an iteration than the two 64-row
+// triangular solves through the fp32 factor.  Relative error 2.2e-16 (checked against numpy over [-630, 0]).
+__device__ __forceinline__ double exp_nonpos(double x) {
+  const double n = rint(x * 1.4426950408889634074);
+  double r = fma(n, -6.93147180369123816490e-01, x);  // ln2 hi
+  r = fma(n, -1.90821492927058770002e-10, r);         // ln2 lo
+  double p = 1.0 / 6227020800.0;                      // 1 / 13!
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
 template <int KERNEL>
 __device__ __forceinline__ double kval(double r2, double sf2) {
-  if (KERNEL == 0) return sf2 * exp(-0.5 * r2);
+  if (KERNEL == 0) return sf2 * exp_nonpos(-0.5 * r2);
   const double s = SQRT5 * sqrt(r2);
-  return sf2 * ((1.0 + s + s * s / 3.0) * exp(-s));
+  return sf2 * ((1.0 + s + s * s / 3.0) * exp_nonpos(-s));
 }
 
 // outT[c][i] = (y ? y[i*k + c] : 0) + sign * (sum_j sf2 k(a_i, b_j) alphaT[c][j] + diag * alphaT[c][i])
 // for i < m (0 beyond), c < k <= KMAX.  As (mpad x d), Bs (npad x d) scaled points, zero rows beyond
 // m / n; alphaT (k x lda) must be zero beyond n.  One workgroup per 64 rows; wave g takes 16 of
 // every 64 columns (lane = row: the column operands are LDS broadcasts); fixed reduction order.
-template <int KERNEL, int D>
+// KC = compile-time bound on the number of target columns (1, 2 or KMAX): no predicated accumulators
+template <int KERNEL, int D, int KC>
 __global__ __launch_bounds__(256) void kmatvec_kernel(const double* __restrict__ As, int64_t m,
                                                      const double* __restrict__ Bs, int64_t npad, int d_rt,
                                                      double sf2, double diag, const double* __restrict__ y,
@@ -41,14 +69,14 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(const double* __restrict__
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   double xa[D > 0 ? D : XMAXD];
   for (int c = 0; c < d; ++c) xa[c] = As[i * d + c];  // padded rows are readable
-  double acc[KMAX];
+  double acc[KC];
 #pragma unroll
-  for (int c = 0; c < KMAX; ++c) acc[c] = 0.0;
+  for (int c = 0; c < KC; ++c) acc[c] = 0.0;
   for (int64_t j0 = 0; j0 < npad; j0 += 64) {
     for (int e = tid; e < 64 * d; e += 256) xb[e] = Bs[j0 * d + e];
     for (int e = tid; e < k * 64; e += 256) ab[e] = alphaT[(int64_t)(e >> 6) * lda + j0 + (e & 63)];
     __syncthreads();
-#pragma unroll 4
+#pragma unroll 8
     for (int jj = g * 16; jj < g * 16 + 16; ++jj) {
       double r2 = 0.0;
       if (D > 0) {
@@ -65,19 +93,19 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(const double* __restrict__
       }
       const double kf = kval<KERNEL>(r2, sf2);
 #pragma unroll
-      for (int c = 0; c < KMAX; ++c)
-        if (c < k) acc[c] += kf * ab[c * 64 + jj];
+      for (int c = 0; c < KC; ++c)
+        if (KC <= 2 || c < k) acc[c] += kf * ab[c * 64 + jj];
     }
     __syncthreads();
   }
   if (g > 0) {
 #pragma unroll
-    for (int c = 0; c < KMAX; ++c) red[((g - 1) * 64 + lane) * KMAX + c] = acc[c];
+    for (int c = 0; c < KC; ++c) red[((g - 1) * 64 + lane) * KMAX + c] = acc[c];
   }
   __syncthreads();
   if (g == 0) {
 #pragma unroll
-    for (int c = 0; c < KMAX; ++c)
+    for (int c = 0; c < KC; ++c)
       if (c < k) {
         double v = acc[c];
         for (int q = 0; q < 3; ++q) v += red[(q * 64 + lane) * KMAX + c];
@@ -124,15 +152,27 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
   if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+template <int KERNEL, int KC>
+void launch_kmatvec_kc(const double* As, int64_t m, int64_t mpad, const double* Bs, int64_t npad, int d, double sf2,
+                       double diag, const double* y, const double* alphaT, int64_t lda, int k, double sign,
+                       double* outT, int64_t ldo, hipStream_t st) {
+  dim3 grid((unsigned)(mpad / 64)), block(256);
+  if (d == 3)
+    hipLaunchKernelGGL((kmatvec_kernel<KERNEL, 3, KC>), grid, block, 0, st, As, m, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo);
+  else
+    hipLaunchKernelGGL((kmatvec_kernel<KERNEL, 0, KC>), grid, block, 0, st, As, m, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo);
+}
+
 template <int KERNEL>
 void launch_kmatvec_k(const double* As, int64_t m, int64_t mpad, const double* Bs, int64_t npad, int d, double sf2,
                       double diag, const double* y, const double* alphaT, int64_t lda, int k, double sign,
                       double* outT, int64_t ldo, hipStream_t st) {
-  dim3 grid((unsigned)(mpad / 64)), block(256);
-  if (d == 3)
-    hipLaunchKernelGGL((kmatvec_kernel<KERNEL, 3>), grid, block, 0, st, As, m, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo);
+  if (k == 1)
+    launch_kmatvec_kc<KERNEL, 1>(As, m, mpad, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo, st);
+  else if (k == 2)
+    launch_kmatvec_kc<KERNEL, 2>(As, m, mpad, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo, st);
   else
-    hipLaunchKernelGGL((kmatvec_kernel<KERNEL, 0>), grid, block, 0, st, As, m, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo);
+    launch_kmatvec_kc<KERNEL, KMAX>(As, m, mpad, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo, st);
 }
 
 }  // namespace
