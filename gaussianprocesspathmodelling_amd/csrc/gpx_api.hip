@@ -1732,7 +1732,7 @@ int gpx_debug_set_delay(uint64_t seed) {
 
 int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t tpb, int32_t c, int32_t* out,
                        int64_t cap, int64_t* count) try {
-  if (!out || !count || tm <= 0 || cap <= 0 || kind < 0 || kind > 2) return GPX_E_ARG;
+  if (!out || !count || tm <= 0 || cap <= 0 || kind < 0 || kind > 3) return GPX_E_ARG;
   if (kind == 1 && (tn <= 0 || P <= 0 || tpb <= 0 || c < 0)) return GPX_E_ARG;
   const int64_t n = debug_tile_map(kind, tm, tn, P, tpb, c, out, cap);
   if (n < 0) return GPX_E_ARG;

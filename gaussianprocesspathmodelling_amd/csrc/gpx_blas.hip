@@ -983,10 +983,12 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
   if (lower == 1) {  // full lower triangle, triangular super-tile enumeration
     const int64_t ts = (tm + 7) / 8;
     dim3 grid((unsigned)(ts * (ts - 1) / 2 * 64 + ts * 36));  // tile_coords<TRI>: no masked slots
+    int band = 0;  // GPX_TRI_BAND = B > 1: banded super-tile order (tile_coords<true>; A/B experiment)
+    if (const char* e = getenv("GPX_TRI_BAND")) band = atoi(e) > 1 ? atoi(e) : 0;
     if (mode == 0)
-      GPX_NT_LAUNCH(true, 0, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+      GPX_NT_LAUNCH(true, 0, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, band, bc, (int)k);
     else
-      GPX_NT_LAUNCH(true, 1, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, 0, bc, (int)k);
+      GPX_NT_LAUNCH(true, 1, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, band, bc, (int)k);
   } else if (lower == 4) {  // C = A W^T, W lower triangular: paired tile columns (mode 1 only)
     int sh;
     dim3 grid((unsigned)rect_grid(tm, (tn + 1) / 2, sh));
@@ -1214,6 +1216,17 @@ int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, i
     for (int64_t b = 0; b < grid; ++b) {
       int ti, tj;
       if (!tile_coords<true>(xcd_chunk_id(b, grid), (int)tm, (int)tm, 8, 0, BcMask{0, 1, 0}, ti, tj)) continue;
+      if (n >= cap) return -1;
+      out[2 * n] = ti;
+      out[2 * n + 1] = tj;
+      ++n;
+    }
+  } else if (kind == 3) {  // lower triangle in the banded super-tile order, band height tn
+    const int64_t ts = (tm + 7) / 8;
+    const int64_t grid = ts * (ts - 1) / 2 * 64 + ts * 36;
+    for (int64_t b = 0; b < grid; ++b) {
+      int ti, tj;
+      if (!tile_coords<true>(xcd_chunk_id(b, grid), (int)tm, (int)tm, 8, (int)tn, BcMask{0, 1, 0}, ti, tj)) continue;
       if (n >= cap) return -1;
       out[2 * n] = ti;
       out[2 * n + 1] = tj;
