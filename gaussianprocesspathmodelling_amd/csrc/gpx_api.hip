@@ -198,6 +198,15 @@ void collect_phases(gpx_handle* h) {
   h->ev_used = 0;
 }
 
+// rocprofv3 --pmc (or a counter input file) exports ROCPROF_COUNTER_COLLECTION=1 into the profiled process.
+// Counter collection serialises kernels across streams in an order of its own, which a stream parked on a
+// device flag (wait_counter_kernel) does not survive — it would spin until its time-out — so the device-side
+// hand-overs switch themselves off there and the schedule falls back to hipEvents (same kernels otherwise).
+bool counters_are_being_collected() {
+  const char* e = getenv("ROCPROF_COUNTER_COLLECTION");
+  return e && atoi(e) != 0;
+}
+
 struct LatencyGuard {  // set_latency_mode(0) on every exit path of a scheduler function
   ~LatencyGuard() { set_latency_mode(0); }
 };
@@ -247,8 +256,8 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
   unsigned* dflag = reinterpret_cast<unsigned*>(info + 9);  // `info` is a 64-byte buffer: [0] pivot, [8] strip counter, [9] step flag
   unsigned seq = 0;
   const bool use_flag = [] {
-    const char* e = getenv("GPX_CHAIN_FLAG");
-    return !(e && atoi(e) == 0);
+    if (const char* e = getenv("GPX_CHAIN_FLAG")) return atoi(e) != 0;
+    return !counters_are_being_collected();  // rocprofv3 --pmc announces itself: hand over by events there
   }();
   if (iw) {
     Wp = iw->W + (o / iw->nbw) * (int64_t)iw->nbw * iw->nbw;
@@ -373,7 +382,7 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
   int rc;
   const bool fuse_env = [] {  // read per call (tests switch it); default OFF: measured equal, see DESIGN.md §5.2
     const char* e = getenv("GPX_FUSED_STRIP");
-    return e && atoi(e) != 0;
+    return e && atoi(e) != 0 && !counters_are_being_collected();
   }();
   unsigned* ctr = reinterpret_cast<unsigned*>(info + 8);  // the info buffer is 64 bytes: [0] pivot, [8] strip counter
   unsigned target = 0;

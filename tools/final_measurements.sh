@@ -1,9 +1,10 @@
 # Round-3 final evidence (one gpurun call): rocprofv3 kernel stats of bench.py, three separate PMC passes
 # (never combined with tracing domains), the C2 stats, then the unprofiled default bench lines.
-# The PMC passes run with GPX_CHAIN_FLAG=0 (and the default two-launch trailing update): counter collection
-# serialises kernels across queues in its own order, which a stream parked on a device flag does not survive
-# (the wait kernel runs before the kernel it waits for until its 15 s time-out).  The kernels the
-# counters are read for (trailing update, kernel build) are the same code either way.
+# Under the PMC passes the library hands over by hipEvents by itself (it sees ROCPROF_COUNTER_COLLECTION=1;
+# GPX_CHAIN_FLAG=0 is exported as well, belt and braces): counter collection serialises kernels across queues in
+# its own order, which a stream parked on a device flag does not survive (the wait kernel runs before the kernel
+# it waits for until its 15 s time-out).  The kernels the counters are read for (trailing update,
+# kernel build) are the same code either way.
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
