@@ -293,7 +293,7 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
     const int64_t oq = o + (int64_t)q * KB;
     T* Aqq = A + oq * ld + oq;
     T* Wq = Winv + (oq / KB) * (KB * KB);
-    ++seq;
+    seq += 2;  // POTF2 writes seq - 1 when it starts ("everything before it on the chain is complete") and seq when it is done
     if (w == 2)
       launch_potf2_128<T>(Aqq, ld, Wq, gidx0 + oq, info, s, iw && use_flag ? dflag : nullptr, seq);
     else
@@ -306,15 +306,24 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
     }
     if (iw) {  // column blocks q .. q + w - 1 of the inverse, behind this step's POTF2
       if (use_flag) {
+        // the part of the extension's walk that lies left of this step's columns needs nothing of this step:
+        // it starts with the step's POTF2 and runs beside it; the rest follows the POTF2
+        if (q > 0) {
+          launch_wait_counter(dflag, seq - 1, info, iw->aux);
+          launch_inv_extend<T>(iw->U, iw->ldu, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), q, q + w, Wp,
+                               iw->nbw, iw->aux, 1);
+        }
         launch_wait_counter(dflag, seq, info, iw->aux);
-      } else {
+      } else {  // the same two launches (the same arithmetic, bit for bit), both behind the step's event
         hipEvent_t e = next_event(h);
         if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (block inverse)");
         HIPCHK(h, hipEventRecord(e, s));
         HIPCHK(h, hipStreamWaitEvent(iw->aux, e, 0));
+        launch_inv_extend<T>(iw->U, iw->ldu, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), q, q + w, Wp, iw->nbw,
+                             iw->aux, 1);
       }
       launch_inv_extend<T>(iw->U, iw->ldu, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), q, q + w, Wp, iw->nbw,
-                           iw->aux);
+                           iw->aux, 2);
     }
     q += w;
   }

@@ -668,6 +668,9 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x;
   const T zero = (T)0;
+  // "begin" mark (flag_val - 1): everything queued before this kernel on its stream is complete — what the
+  // "pre" part of the inverse extension waits for; no fence needed (the kernel boundary was the release)
+  if (flag && tid == 0) __hip_atomic_store(flag, flag_val - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   GPX_STAMP(0);
   {
     // all 16 loads of a thread in flight before the first LDS write: the tile comes from HBM /
@@ -729,6 +732,7 @@ __global__ __launch_bounds__(256) void potf2_128_kernel(T* __restrict__ A, int64
   const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const T zero = (T)0;
+  if (flag && tid == 0) __hip_atomic_store(flag, flag_val - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // "begin": see potf2_64_kernel
   T* A21 = A + (int64_t)64 * lda;
   T* A22 = A21 + 64;
   // lower 16-tiles (tr, tc), tc <= tr, of the 64x64 block A22 in row-major order idx = tr (tr + 1) / 2 + tc;
@@ -866,21 +870,36 @@ __device__ __forceinline__ void store_tile_transposed(T* Wt, int64_t ldw, const 
 // block upper triangular (slab s is zero left of column block s — the inverse being built from
 // the identity), so slab s starts its contraction at column 64 s.  Wt != null: the solved block
 // is also written transposed, Wt[(64 jb + c) * ldw + 64 slab + r] = X[r][64 jb + c].
+// phase 0: the whole walk.  phase 1 ("pre"): only the part of every block's contraction that lies LEFT of
+// column block jb_lo — X_jb -= sum_{kb < jb_lo} X_kb L[jb, kb]^T for jb in [jb_lo, jb_hi), no inverse — which
+// needs nothing the current diagonal step produces; phase 2 ("post"): the rest (the blocks inside
+// [jb_lo, jb), then the inverse).  The extension of a panel's block inverse is split that way (round 3): the
+// long part of its walk runs BESIDE the step's POTF2 instead of behind it.
 template <typename T, int KSUB>
 __global__ __launch_bounds__(256, KSUB >= 4 ? 1 : 2) void trsm_rlt_kernel(T* X, int64_t ldx, const T* L, int64_t ldl,
                                                           const T* Winv, int jb_lo, int jb_hi, T* P, int64_t ldp,
-                                                          int tri, T* Wt, int64_t ldw) {
+                                                          int tri, T* Wt, int64_t ldw, int phase) {
   __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 64, 64, KSUB>::SMEM_ELEMS];
   __builtin_amdgcn_s_setprio(2);  // panel solve is on the critical path of the look-ahead
   T* Xs = X + (int64_t)blockIdx.x * 64 * ldx;
   T* Ps = P ? P + (int64_t)blockIdx.x * 64 * ldp : nullptr;
   const int k0 = tri ? (int)blockIdx.x * 64 : 0;
   typename Num<T>::v4 acc[2][2];
+  if (phase == 1) {
+    const int kend = jb_lo * 64;
+    if (kend <= k0) return;
+    const int jb = jb_lo + (int)blockIdx.y;  // the blocks of a "pre" walk do not depend on each other: one per workgroup
+    zero_acc(acc);
+    gemm_tile_g<T, 64, 64, 2, KSUB>(Xs + k0, ldx, L + (int64_t)jb * 64 * ldl + k0, ldl, kend - k0, acc, smem);
+    store_tile<T, 64, 64, 0>(Xs + jb * 64, ldx, acc);
+    return;
+  }
   for (int jb = jb_lo; jb < jb_hi; ++jb) {
     T* Xj = Xs + jb * 64;
-    if (jb * 64 > k0) {
+    const int ks = phase == 2 ? max(k0, jb_lo * 64) : k0;  // phase 2: what lies left of block jb_lo is in already
+    if (jb * 64 > ks) {
       zero_acc(acc);
-      gemm_tile_g<T, 64, 64, 2, KSUB>(Xs + k0, ldx, L + (int64_t)jb * 64 * ldl + k0, ldl, jb * 64 - k0, acc, smem);
+      gemm_tile_g<T, 64, 64, 2, KSUB>(Xs + ks, ldx, L + (int64_t)jb * 64 * ldl + ks, ldl, jb * 64 - ks, acc, smem);
       store_tile<T, 64, 64, 0>(Xj, ldx, acc);
       __syncthreads();
     }
@@ -1048,26 +1067,29 @@ void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
   // per barrier; many slabs: the plain engine, whose occupancy hides the latency
   if (g_latency_mode && rows / 64 <= cu_count())
     hipLaunchKernelGGL((trsm_rlt_kernel<T, Num<T>::KS64>), dim3((unsigned)(rows / 64)), dim3(256), 0, st, X, ldx, L, ldl,
-                       Winv, 0, nb / 64, P, ldp, 0, (T*)nullptr, (int64_t)0);
+                       Winv, 0, nb / 64, P, ldp, 0, (T*)nullptr, (int64_t)0, 0);
   else
     hipLaunchKernelGGL((trsm_rlt_kernel<T, 1>), dim3((unsigned)(rows / 64)), dim3(256), 0, st, X, ldx, L, ldl,
-                       Winv, 0, nb / 64, P, ldp, 0, (T*)nullptr, (int64_t)0);
+                       Winv, 0, nb / 64, P, ldp, 0, (T*)nullptr, (int64_t)0, 0);
 }
 
 template <typename T>
 void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv, int q0, int q1, T* W,
-                       int64_t ldw, hipStream_t st) {
+                       int64_t ldw, hipStream_t st, int phase) {
   debug_delay(st);
   if (((uintptr_t)U | (uintptr_t)(ldu * (int64_t)sizeof(T))) % 128 != 0) {
     g_launch_error.store(1);
     return;
   }
+  if (phase == 1 && q0 == 0) return;  // nothing lies left of the first block
+  // "pre": only the slabs that start left of block q0 have work, one workgroup per (slab, block)
+  const dim3 grid = phase == 1 ? dim3((unsigned)q0, (unsigned)(q1 - q0)) : dim3((unsigned)q1);
   if (g_latency_mode)
-    hipLaunchKernelGGL((trsm_rlt_kernel<T, Num<T>::KS64>), dim3((unsigned)q1), dim3(256), 0, st, U, ldu, L, ldl, Winv, q0, q1,
-                       (T*)nullptr, (int64_t)0, 1, W, ldw);
+    hipLaunchKernelGGL((trsm_rlt_kernel<T, Num<T>::KS64>), grid, dim3(256), 0, st, U, ldu, L, ldl, Winv, q0, q1,
+                       (T*)nullptr, (int64_t)0, 1, W, ldw, phase);
   else
-    hipLaunchKernelGGL((trsm_rlt_kernel<T, 1>), dim3((unsigned)q1), dim3(256), 0, st, U, ldu, L, ldl, Winv, q0, q1,
-                       (T*)nullptr, (int64_t)0, 1, W, ldw);
+    hipLaunchKernelGGL((trsm_rlt_kernel<T, 1>), grid, dim3(256), 0, st, U, ldu, L, ldl, Winv, q0, q1,
+                       (T*)nullptr, (int64_t)0, 1, W, ldw, phase);
 }
 
 template <typename T>
@@ -1280,7 +1302,7 @@ extern "C" int gpx_debug_read_syrk_clock(long long* out) {
                                    hipStream_t);                                                        \
   template void launch_trsm_rln<T>(T*, int64_t, int64_t, const T*, int64_t, const T*, int, hipStream_t); \
   template void launch_inv_extend<T>(T*, int64_t, const T*, int64_t, const T*, int, int, T*, int64_t,   \
-                                     hipStream_t);                                                      \
+                                     hipStream_t, int);                                                 \
   template void launch_gemm_nt<T>(int, T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,      \
                                   int64_t, int64_t, int, int, hipStream_t);                             \
   template void launch_gemm_nt_fixed<T>(int, T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t, \

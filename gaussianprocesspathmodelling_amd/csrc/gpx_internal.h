@@ -67,7 +67,7 @@ void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
 // row blocks [q0, q1) of W = L^-1 (ldw).  Needs the 64-block inverses and rows of L up to q1.
 template <typename T>
 void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv, int q0, int q1, T* W,
-                       int64_t ldw, hipStream_t st);
+                       int64_t ldw, hipStream_t st, int phase = 0);  // 0 whole, 1 "pre" (left of block q0 only), 2 "post"
 // Latency mode of the calling host thread (default off): the 64-tile launches (launch_gemm_nt with an
 // under-filled 128-grid, launch_trsm_rlt / launch_inv_extend with few slabs) then stage several k-steps per
 // barrier — 64 or 128 KB of LDS per workgroup instead of 32 — which shortens every latency-bound K walk
