@@ -448,6 +448,16 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       HIPCHK(h, hipStreamWaitEvent(s1, e_init, 0));  // counter reset + panel 0 before the parked stream's first poll
     }
   }
+  const bool split_env = [] {  // read per call (tests switch it)
+    const char* e = getenv("GPX_SPLIT_STRIP");
+    return !e || atoi(e) != 0;
+  }() && !fuse_env;  // (the fused update keeps its own hand-over)
+  hipEvent_t e_main = nullptr;  // split strip: "the main stream's work on the trailing matrix so far is complete"
+  if (split_env && n > nb) {
+    e_main = next_event(h);
+    if (!e_main) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+    HIPCHK(h, hipEventRecord(e_main, s0));  // panel 0 ran on the main stream
+  }
   int step = 0;
   for (int64_t o = 0; o < n; o += nb, ++step) {
     const int nbp = (int)std::min<int64_t>(nb, n - o);
@@ -481,6 +491,54 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       }
       HIPCHK(h, hipEventRecord(e_panel, s1));
       if (is_fused(t0)) bordered_update(t0, Pn, s1);  // for update p+1: off the chain, beside the rest of update p
+      HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
+      continue;
+    }
+    if (split_env) {
+      // SPLIT STRIP (round 3, the default): of the strip only the next DIAGONAL block is on the chain.  It is
+      // updated on the look-ahead stream itself, right behind the panel solve that produced its operand (no
+      // hand-over between streams on the chain; 64-tiles in latency mode: a K = nb walk of a 64-tile is a
+      // quarter of a 128-tile's), after the previous panel's REST (which also touched the block) is complete.
+      // The rows BELOW it are needed only by the next panel solve, one diagonal chain later: they are updated
+      // on the main stream, beside that chain, followed by the REST.
+      if (e_main) HIPCHK(h, hipStreamWaitEvent(s1, e_main, 0));
+      {
+        PhaseScope ps(h, &h->tm.chol_strip, profile, s1);
+        launch_gemm_nt<T>(tile, A + t0 * ld + t0, ld, Pc, ldp, Pc, ldp, nbn, nbn, nbp, 1, 0, s1);
+      }
+      {
+        PhaseScope ps(h, &h->tm.chol_diag, profile, s1);
+        if ((rc = diag_enqueue(h, A, ld, t0, nbn, Winv, info, gidx0, s1, iw))) return rc;
+      }
+      {
+        PhaseScope ps(h, &h->tm.chol_strip, profile);
+        if (nrest > 0)
+          launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + t0, ld, Pc + (int64_t)nbn * ldp, ldp, Pc, ldp, nrest, nbn, nbp, 0,
+                            0, s0);
+        bordered_update(o, Pc, s0);
+      }
+      hipEvent_t e_below = next_event(h);
+      if (!e_below) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+      HIPCHK(h, hipEventRecord(e_below, s0));
+      HIPCHK(h, hipStreamWaitEvent(s1, e_below, 0));
+      {
+        PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
+        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest, nx, Winv, Pn, ldp, s1, iw, (step + 1) & 1))) return rc;
+      }
+      HIPCHK(h, hipEventRecord(e_panel, s1));
+      if (nrest > 0) {
+        const bool big = gemm_nt_tile(tile, nrest, nrest, 1) == 128;
+        PhaseScope ps(h, big ? &h->tm.chol_syrk : &h->tm.chol_strip, profile);
+        launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + (t0 + nbn), ld, Pc + (int64_t)nbn * ldp, ldp,
+                          Pc + (int64_t)nbn * ldp, ldp, nrest, nrest, nbp, 1, 0, s0);
+        if (big) {
+          h->tm.syrk_flops += (double)nrest * (double)(nrest + 1) * (double)nbp;
+          h->tm.syrk_launches += 1;
+        }
+      }
+      e_main = next_event(h);
+      if (!e_main) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+      HIPCHK(h, hipEventRecord(e_main, s0));
       HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
       continue;
     }

@@ -52,6 +52,13 @@ def test_fused_trailing_update_does_not_depend_on_stream_timing(monkeypatch, del
     run_delay_case(monkeypatch, delay, 12288, 300, {}, False, False)
 
 
+def test_unsplit_strip_does_not_depend_on_stream_timing(monkeypatch, delay):
+    """GPX_SPLIT_STRIP=0: the round-2 schedule (the whole strip on the main stream, handed to the look-ahead
+    stream by an event) stays selectable for A/B measurements; the default (split) is what every other case runs."""
+    monkeypatch.setenv("GPX_SPLIT_STRIP", "0")
+    run_delay_case(monkeypatch, delay, 9000, 300, {}, False, False)
+
+
 def run_delay_case(monkeypatch, delay, N, M, kw, grad, small):
     if small:
         monkeypatch.setenv("GPX_NB_SHARD", "256")

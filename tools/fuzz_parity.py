@@ -40,9 +40,10 @@ def one_case(rng, c):
     mr, vr = ref.predict(Xs)
     kw = {}
     # round-3 schedule switches, at random: 64-wide diagonal steps, hipEvent hand-over of the diagonal chain
-    variant = {"GPX_DIAG_STEP": str(rng.choice(["128", "64"])), "GPX_CHAIN_FLAG": str(rng.choice(["1", "0"]))}
+    variant = {"GPX_DIAG_STEP": str(rng.choice(["128", "64"])), "GPX_CHAIN_FLAG": str(rng.choice(["1", "0"])),
+               "GPX_SPLIT_STRIP": str(rng.choice(["1", "0"]))}
     os.environ.update(variant)
-    tag += f" step={variant['GPX_DIAG_STEP']} flag={variant['GPX_CHAIN_FLAG']}"
+    tag += f" step={variant['GPX_DIAG_STEP']} flag={variant['GPX_CHAIN_FLAG']} split={variant['GPX_SPLIT_STRIP']}"
     if ndev > 1:
         os.environ["GPX_SHARD_REPLICATE"] = str(repl)
         os.environ["GPX_NB_SHARD"] = str(nbs)
@@ -63,6 +64,7 @@ def one_case(rng, c):
     finally:
         os.environ.pop("GPX_DIAG_STEP", None)
         os.environ.pop("GPX_CHAIN_FLAG", None)
+        os.environ.pop("GPX_SPLIT_STRIP", None)
         os.environ.pop("GPX_SHARD_REPLICATE", None)
         os.environ.pop("GPX_NB_SHARD", None)
     return tag, e
