@@ -72,6 +72,7 @@ struct gpx_handle {
   int nb_pred = 1024;  // block width of the variance TRSM
   hipStream_t st = nullptr;   // main stream
   hipStream_t st2 = nullptr;  // look-ahead (panel) stream, high priority
+  hipStream_t stm = nullptr;  // main stream with a CU mask (GPX_CU_RESERVE CUs left to the chain); null: none
   hipStream_t st3 = nullptr;  // side stream of the diagonal chain: in-block SYRKs, block inverses
   hipStream_t st4 = nullptr;  // copy stream: solved panels / blocks back into their matrices
   std::string err;
@@ -352,12 +353,17 @@ int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int
   const T* Wp = iw->W + (o / iw->nbw) * (int64_t)iw->nbw * iw->nbw;
   HIPCHK(h, hipStreamWaitEvent(s, iw->ready, 0));
   if (iw->copied[set]) HIPCHK(h, hipStreamWaitEvent(s, iw->copied[set], 0));  // P[set] is about to be overwritten
-  if (rows_main > 0)
-    launch_gemm_nt<T>((rows_main % 128 == 0 && nbp % 128 == 0) ? 128 : 64, P, ldp, Apanel, ld, Wp, iw->nbw,
-                      rows_main, nbp, nbp, 4, 1, s);
-  if (nx > 0)
-    launch_gemm_nt<T>(64, P + rows_main * ldp, ldp, Apanel + rows_main * ld, ld, Wp, iw->nbw, nx, nbp, nbp, 4, 1,
-                      s);
+  const int tile_main = gemm_nt_tile((rows_main % 128 == 0 && nbp % 128 == 0) ? 128 : 64, rows_main, nbp, 4);
+  if (rows_main > 0 && nx > 0 && tile_main == 64) {
+    // the bordered rows lie directly below the matrix rows, in A and in P: with 64-tiles on both, ONE launch
+    // (as a launch of its own the 64-row product is a serial K = nb walk of ~37 us on the chain)
+    launch_gemm_nt_fixed<T>(64, P, ldp, Apanel, ld, Wp, iw->nbw, rows, nbp, nbp, 4, 1, s);
+  } else {
+    if (rows_main > 0) launch_gemm_nt_fixed<T>(tile_main, P, ldp, Apanel, ld, Wp, iw->nbw, rows_main, nbp, nbp, 4, 1, s);
+    if (nx > 0)
+      launch_gemm_nt<T>(64, P + rows_main * ldp, ldp, Apanel + rows_main * ld, ld, Wp, iw->nbw, nx, nbp, nbp, 4, 1,
+                        s);
+  }
   hipEvent_t e = next_event(h);
   if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (panel copy)");
   HIPCHK(h, hipEventRecord(e, s));
@@ -452,6 +458,11 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     const char* e = getenv("GPX_SPLIT_STRIP");
     return !e || atoi(e) != 0;
   }() && !fuse_env;  // (the fused update keeps its own hand-over)
+  const int rest_split = [] {  // trailing rows (in panels) up to which the REST hands its first column block over early
+    const char* e = getenv("GPX_REST_SPLIT");
+    return e ? atoi(e) : 16;
+  }();
+  hipStream_t cur_main = s0;
   hipEvent_t e_main = nullptr;  // split strip: "the main stream's work on the trailing matrix so far is complete"
   if (split_env && n > nb) {
     e_main = next_event(h);
@@ -495,6 +506,15 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       continue;
     }
     if (split_env) {
+      // the main stream of this iteration: the CU-masked one once the chain sets the pace (GPX_CU_RESERVE)
+      hipStream_t sm = (h->stm && ntrail <= (int64_t)(rest_split + 1) * nb) ? h->stm : s0;
+      if (sm != cur_main) {  // everything queued on the old one first (stream order carries the buffer hazards)
+        hipEvent_t e_sw = next_event(h);
+        if (!e_sw) return fail(h, GPX_E_HIP, "hipEventCreate failed (stream switch)");
+        HIPCHK(h, hipEventRecord(e_sw, cur_main));
+        HIPCHK(h, hipStreamWaitEvent(sm, e_sw, 0));
+        cur_main = sm;
+      }
       // SPLIT STRIP (round 3, the default): of the strip only the next DIAGONAL block is on the chain.  It is
       // updated on the look-ahead stream itself, right behind the panel solve that produced its operand (no
       // hand-over between streams on the chain; 64-tiles in latency mode: a K = nb walk of a 64-tile is a
@@ -506,40 +526,64 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
         PhaseScope ps(h, &h->tm.chol_strip, profile, s1);
         launch_gemm_nt<T>(tile, A + t0 * ld + t0, ld, Pc, ldp, Pc, ldp, nbn, nbn, nbp, 1, 0, s1);
       }
+      // The host enqueues the main stream's whole iteration BEFORE the diagonal chain's ~50 small launches: the
+      // GPU runs the chain about as fast as the host can enqueue it (N = 8192: the update used to reach the GPU
+      // 0.5 ms after the panel it needs, and then collided with the NEXT panel solve and diagonal-block update).
+      {
+        PhaseScope ps(h, &h->tm.chol_strip, profile, sm);
+        if (nrest > 0)
+          launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + t0, ld, Pc + (int64_t)nbn * ldp, ldp, Pc, ldp, nrest, nbn, nbp, 0,
+                            0, sm);
+        bordered_update(o, Pc, sm);
+      }
+      hipEvent_t e_below = next_event(h);
+      if (!e_below) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+      HIPCHK(h, hipEventRecord(e_below, sm));
+      // REST.  Where the chain, not the update, sets the pace (the last `rest_split` panels' worth of trailing
+      // rows: all of N = 8192, the tail of N = 65536), the column block of the panel AFTER next goes first, as a
+      // launch of its own, and the look-ahead stream's next diagonal-block update waits for that launch only:
+      // the chain then never waits for the bulk of an update (it used to, for every early panel of N = 8192,
+      // where update and chain take about the same time).  The panel buffer this update reads is rewritten two
+      // panel solves later, behind the next "rows below" event of this stream, i.e. behind all of this update.
+      const int nbn2 = (int)std::min<int64_t>(nb, nrest);
+      const bool ahead = nrest > nbn2 && nrest <= (int64_t)rest_split * nb;
+      T* Cr = A + (t0 + nbn) * ld + (t0 + nbn);
+      const T* Pr = Pc + (int64_t)nbn * ldp;
+      if (ahead) {
+        {
+          PhaseScope ps(h, &h->tm.chol_strip, profile, sm);
+          launch_gemm_nt<T>(tile, Cr, ld, Pr, ldp, Pr, ldp, nrest, nbn2, nbp, 2, 0, sm);
+        }
+        e_main = next_event(h);
+        if (!e_main) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+        HIPCHK(h, hipEventRecord(e_main, sm));
+      }
+      const int64_t nr = ahead ? nrest - nbn2 : nrest, off = ahead ? nbn2 : 0;
+      if (nr > 0) {
+        const bool big = gemm_nt_tile(tile, nr, nr, 1) == 128;
+        PhaseScope ps(h, big ? &h->tm.chol_syrk : &h->tm.chol_strip, profile, sm);
+        launch_gemm_nt<T>(tile, Cr + off * ld + off, ld, Pr + off * ldp, ldp, Pr + off * ldp, ldp, nr, nr, nbp, 1, 0, sm);
+        if (big) {
+          h->tm.syrk_flops += (double)nr * (double)(nr + 1) * (double)nbp;
+          h->tm.syrk_launches += 1;
+        }
+      }
+      if (!ahead) {
+        e_main = next_event(h);
+        if (!e_main) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
+        HIPCHK(h, hipEventRecord(e_main, sm));
+      }
       {
         PhaseScope ps(h, &h->tm.chol_diag, profile, s1);
         if ((rc = diag_enqueue(h, A, ld, t0, nbn, Winv, info, gidx0, s1, iw))) return rc;
       }
-      {
-        PhaseScope ps(h, &h->tm.chol_strip, profile);
-        if (nrest > 0)
-          launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + t0, ld, Pc + (int64_t)nbn * ldp, ldp, Pc, ldp, nrest, nbn, nbp, 0,
-                            0, s0);
-        bordered_update(o, Pc, s0);
-      }
-      hipEvent_t e_below = next_event(h);
-      if (!e_below) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
-      HIPCHK(h, hipEventRecord(e_below, s0));
       HIPCHK(h, hipStreamWaitEvent(s1, e_below, 0));
       {
         PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
         if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest, nx, Winv, Pn, ldp, s1, iw, (step + 1) & 1))) return rc;
       }
       HIPCHK(h, hipEventRecord(e_panel, s1));
-      if (nrest > 0) {
-        const bool big = gemm_nt_tile(tile, nrest, nrest, 1) == 128;
-        PhaseScope ps(h, big ? &h->tm.chol_syrk : &h->tm.chol_strip, profile);
-        launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + (t0 + nbn), ld, Pc + (int64_t)nbn * ldp, ldp,
-                          Pc + (int64_t)nbn * ldp, ldp, nrest, nrest, nbp, 1, 0, s0);
-        if (big) {
-          h->tm.syrk_flops += (double)nrest * (double)(nrest + 1) * (double)nbp;
-          h->tm.syrk_launches += 1;
-        }
-      }
-      e_main = next_event(h);
-      if (!e_main) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
-      HIPCHK(h, hipEventRecord(e_main, s0));
-      HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
+      HIPCHK(h, hipStreamWaitEvent(sm, e_panel, 0));
       continue;
     }
     {  // STRIP: rows [t0, n) x cols [t0, t0+nbn), tiles on/below the diagonal
@@ -581,6 +625,12 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       }
     }
     HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
+  }
+  if (cur_main != s0) {
+    hipEvent_t e = next_event(h);
+    if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (join)");
+    HIPCHK(h, hipEventRecord(e, cur_main));
+    HIPCHK(h, hipStreamWaitEvent(s0, e, 0));
   }
   if (iw) {  // join the side and copy streams: the last inverse and every panel copy-back are in W / A
     for (hipStream_t sj : {iw->aux, h->st4}) {
@@ -1327,6 +1377,22 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) try {
     delete h;
     return fail(nullptr, GPX_E_HIP, "gpx_create: hipSetDevice/hipStreamCreate failed");
   }
+  // GPX_CU_RESERVE = k: the trailing updates of the chain-bound panels run on a stream whose CU mask leaves
+  // k CUs (mask bits 0 .. k-1: one per XCD, round robin) to the look-ahead chain (tools/cumask_probe.hip)
+  if (const char* e = getenv("GPX_CU_RESERVE")) {
+    int ncu = 0;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+    const int k = atoi(e);
+    if (k > 0 && k < ncu) {
+      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0xffffffffu);
+      if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1;
+      for (int b = 0; b < k; ++b) mask[b / 32] &= ~(1u << (b % 32));
+      if (hipExtStreamCreateWithCUMask(&h->stm, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        h->stm = nullptr;
+        (void)hipGetLastError();
+      }
+    }
+  }
   *out = h;
   return GPX_OK;
 }
@@ -1344,6 +1410,7 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st2) (void)hipStreamSynchronize(h->st2);
   if (h->st3) (void)hipStreamSynchronize(h->st3);
   if (h->st4) (void)hipStreamSynchronize(h->st4);
+  if (h->stm) (void)hipStreamSynchronize(h->stm);
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->MTpart, &h->var, &h->meanout, &h->G, &h->Pglob,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
@@ -1356,6 +1423,7 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st2) (void)hipStreamDestroy(h->st2);
   if (h->st3) (void)hipStreamDestroy(h->st3);
   if (h->st4) (void)hipStreamDestroy(h->st4);
+  if (h->stm) (void)hipStreamDestroy(h->stm);
   delete h;
 }
 

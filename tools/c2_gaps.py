@@ -34,3 +34,28 @@ for i in range(len(pot) - 1):
     tot["step"] += fit[pot[i + 1]]["s"] - fit[pot[i]]["s"]; cnt["step"] += 1
     tot["potf2"] += fit[pot[i]]["e"] - fit[pot[i]]["s"]
 print("mean step of %d columns (potf2 start to next potf2 start, inside a block): %.1f us; potf2 itself %.1f us" % (1024 // SPB, tot["step"] / cnt["step"] / 1e3, tot["potf2"] / cnt["step"] / 1e3))
+# block boundary: every kernel from the last potf2 of block b to the first potf2 of block b + 1 (the part of the
+# chain that is not diagonal steps: last in-block work, inverse post part, panel solve, update of the next
+# diagonal block), us from the end of that last potf2
+for blk in (0, 1, 2, 3, 6):
+    a, b = pot[blk * SPB + SPB - 1], pot[(blk + 1) * SPB]
+    t0 = fit[a]["e"]
+    print(f"--- boundary between diagonal blocks {blk} and {blk + 1}: {(fit[b]['s'] - t0)/1e3:.1f} us from the end of the last potf2 to the start of the next ---")
+    for r in fit[a + 1:b + 1]:
+        if r["e"] < t0: continue
+        nm = r["Kernel_Name"]
+        print(f'   {short(nm):8s}[q{r["Queue_Id"]}] {(r["s"]-t0)/1e3:8.1f} +{(r["e"]-r["s"])/1e3:7.1f}   grid {r.get("Grid_Size", "?")}')
+bt = [fit[pot[(k + 1) * SPB]]["s"] - fit[pot[k * SPB + SPB - 1]]["e"] for k in range(len(pot) // SPB - 1)]
+print("block boundaries (us):", " ".join(f"{v/1e3:.0f}" for v in bt), " sum %.2f ms" % (sum(bt) / 1e6))
+# the main stream's kernels of the last fit (everything that is not the chain's small launches), ms from the fit's start
+if "--main" in sys.argv:
+    f0 = fit[0]["s"]
+    qmain = fit[pot[0]]["Queue_Id"]      # the prologue's potf2 runs on the main stream
+    print("--- main stream (queue %s) and the look-ahead stream's larger launches: start ms + duration us ---" % qmain)
+    for r in fit:
+        d = (r["e"] - r["s"]) / 1e3
+        nm = short(r["Kernel_Name"])
+        if (r["Queue_Id"] == qmain and nm not in ("potf2", "trsm") and d > 15) or (nm in ("ltri",) or (nm == "syrk64" and d > 25)):
+            print(f'   {nm:8s}[q{r["Queue_Id"]}] {(r["s"]-f0)/1e6:8.3f} +{d:7.1f}')
+    for k in range(len(pot) // SPB):
+        print(f"   diag block {k}: first potf2 at {(fit[pot[k*SPB]]['s']-f0)/1e6:.3f} ms, last ends {(fit[pot[k*SPB+SPB-1]]['e']-f0)/1e6:.3f} ms")

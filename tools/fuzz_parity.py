@@ -41,7 +41,8 @@ def one_case(rng, c):
     kw = {}
     # round-3 schedule switches, at random: 64-wide diagonal steps, hipEvent hand-over of the diagonal chain
     variant = {"GPX_DIAG_STEP": str(rng.choice(["128", "64"])), "GPX_CHAIN_FLAG": str(rng.choice(["1", "0"])),
-               "GPX_SPLIT_STRIP": str(rng.choice(["1", "0"]))}
+               "GPX_SPLIT_STRIP": str(rng.choice(["1", "0"])),
+               "GPX_REST_SPLIT": str(rng.choice(["16", "0", "2"]))}
     os.environ.update(variant)
     tag += f" step={variant['GPX_DIAG_STEP']} flag={variant['GPX_CHAIN_FLAG']} split={variant['GPX_SPLIT_STRIP']}"
     if ndev > 1:
@@ -65,6 +66,7 @@ def one_case(rng, c):
         os.environ.pop("GPX_DIAG_STEP", None)
         os.environ.pop("GPX_CHAIN_FLAG", None)
         os.environ.pop("GPX_SPLIT_STRIP", None)
+        os.environ.pop("GPX_REST_SPLIT", None)
         os.environ.pop("GPX_SHARD_REPLICATE", None)
         os.environ.pop("GPX_NB_SHARD", None)
     return tag, e
