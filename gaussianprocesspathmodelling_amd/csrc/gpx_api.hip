@@ -237,6 +237,7 @@ struct InvWork {
   hipStream_t aux = nullptr;
   hipEvent_t ready = nullptr;      // recorded on aux when the inverse of the last enqueued block is complete
   hipEvent_t copied[2] = {};       // copy-back of the panel last written into P buffer 0 / 1 (copy stream)
+  unsigned seq = 0;                // step flag's last value (info[9]): counts on from block to block of one factorisation
 };
 
 // diagonal block [o, o+nbp) on stream s.  iw != null: after the POTF2 of every 64-column step the
@@ -255,7 +256,7 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
   // serialises kernels across queues in an order of its own; the parked wait kernel then runs before the POTF2 it
   // waits for and only its time-out ends the stand-off — measured: the bench dies after 15 s).
   unsigned* dflag = reinterpret_cast<unsigned*>(info + 9);  // `info` is a 64-byte buffer: [0] pivot, [8] strip counter, [9] step flag
-  unsigned seq = 0;
+  unsigned seq = iw ? iw->seq : 0;
   const bool use_flag = [] {
     if (const char* e = getenv("GPX_CHAIN_FLAG")) return atoi(e) != 0;
     return !counters_are_being_collected();  // rocprofv3 --pmc announces itself: hand over by events there
@@ -266,7 +267,9 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
     // buffer that earlier work on s (or, through its waits, on other ranks) is still reading
     hipEvent_t e0 = next_event(h);
     if (!e0) return fail(h, GPX_E_HIP, "hipEventCreate failed (block inverse)");
-    HIPCHK(h, hipMemsetAsync(dflag, 0, sizeof(unsigned), s));  // the block's step flag (info[9]); the chain's stream owns it
+    // the step flag (info[9]) is reset in front of the FIRST block only; later blocks count on (one memset and
+    // the gaps around it less on the chain per block; every stream that polls the flag starts behind e0)
+    if (seq == 0) HIPCHK(h, hipMemsetAsync(dflag, 0, sizeof(unsigned), s));
     HIPCHK(h, hipEventRecord(e0, s));
     HIPCHK(h, hipStreamWaitEvent(iw->aux, e0, 0));
     HIPCHK(h, hipMemsetAsync(iw->U, 0, (size_t)iw->nbw * iw->ldu * sizeof(T), iw->aux));
@@ -329,6 +332,7 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
     q += w;
   }
   if (iw) {
+    iw->seq = seq;
     iw->ready = next_event(h);
     if (!iw->ready) return fail(h, GPX_E_HIP, "hipEventCreate failed (block inverse)");
     HIPCHK(h, hipEventRecord(iw->ready, iw->aux));

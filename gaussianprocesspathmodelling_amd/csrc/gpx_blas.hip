@@ -494,6 +494,9 @@ __device__ __forceinline__ void potf2_lds(T* __restrict__ Wk, T* __restrict__ Wi
       for (int r = 0; r < 4; ++r) R[sl][r] = Wk[(tr * 16 + Num<T>::drow(l4, r)) * PLD + tc * 16 + l15];
     }
   }
+#ifndef GPX_POTF2_UNROLL
+#pragma unroll 1
+#endif
   for (int j = 0; j < 64; j += PW) {
     // ---- phase A: PW x PW diagonal factor (redundant per thread, right-looking in
     //      registers) + this thread's panel row
@@ -1049,7 +1052,18 @@ template <typename T>
 void launch_potf2_128(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st, unsigned* flag,
                       unsigned flag_val) {
   debug_delay(st);
-  hipLaunchKernelGGL(potf2_128_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, Winv, gidx0, info, flag, flag_val);
+  // GPX_POTF2_EXCL=1 (experiment, with GPX_CU_RESERVE): pad the workgroup's LDS to the CU's whole 160 KB, so that
+  // it is only ever placed on an EMPTY CU (one the masked update stream leaves alone)
+  static const unsigned excl = [] {
+    const char* e = getenv("GPX_POTF2_EXCL");
+    if (!e || atoi(e) == 0) return 0u;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(potf2_128_kernel<T>)) != hipSuccess) return 0u;
+    const unsigned pad = 160u * 1024u - (unsigned)fa.sharedSizeBytes;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+    return pad;
+  }();
+  hipLaunchKernelGGL(potf2_128_kernel<T>, dim3(1), dim3(256), excl, st, A, lda, Winv, gidx0, info, flag, flag_val);
 }
 
 template <typename T>

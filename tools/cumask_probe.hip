@@ -35,6 +35,13 @@ static void run(hipStream_t st, const char* tag) {
   }
   size_t tot = 0;
   printf("%s\n", tag);
+  {  // is workgroup i on XCC i % 8 (what the library's XCD-aware tile maps assume)?
+    int same = 0;
+    for (int i = 0; i < G; ++i) same += (h[2 * i] & 0xf) == (unsigned)(i % 8);
+    printf("  workgroups with xcc == blockIdx %% 8: %d of %d; first 32 blocks' xcc:", same, G);
+    for (int i = 0; i < 32; ++i) printf(" %u", h[2 * i] & 0xf);
+    printf("\n");
+  }
   for (auto& kv : cus) {
     tot += kv.second.size();
     printf("  xcc %u: %zu CUs:", kv.first, kv.second.size());
