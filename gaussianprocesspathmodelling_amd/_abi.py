@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgpx.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 KERNEL_IDS = {"rbf": 0, "matern52": 1}
 DTYPE_IDS = {"float64": 0, "float32": 1, "mixed": 2}
@@ -65,6 +65,8 @@ SIGNATURES = {
     "gpx_fit": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _PD, C.c_int32,
                           C.c_double, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_int64)]),
     "gpx_predict": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
+    "gpx_fit_predict": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _PD, C.c_int32, C.c_double, C.c_double,
+                                  C.c_double, _P, C.c_int64, _P, _P, C.c_int32, C.POINTER(C.c_int64)]),
     "gpx_get_alpha": (C.c_int, [_P, _P]),
     "gpx_lml_grad": (C.c_int, [_P, _PD, _PD]),
     "gpx_logdet": (C.c_int, [_P, _PD]),

@@ -395,7 +395,7 @@ int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int
 template <typename T>
 int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T* P0, T* P1,
                  int64_t ldp, int* info, int64_t gidx0, bool profile, int64_t nx = 0,
-                 InvWork<T>* iw = nullptr) {
+                 InvWork<T>* iw = nullptr, int64_t nxa = 0) {
   hipStream_t s0 = h->st, s1 = h->st2;
   T* Pbuf[2] = {P0, P1};
   int rc;
@@ -424,6 +424,14 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     launch_gemm_nt<T>(nx % 128 == 0 && ntrail % 128 == 0 ? 128 : 64, A + n * ld + t0, ld, Pc + ntrail * ldp, ldp, Pc,
                       ldp, nx, ntrail, nbp, 0, 0, s);
   };
+  // bordered rows [n + r0, n + r0 + nr) x matrix columns [c0, c0 + nc), panel at offset o (split schedule)
+  auto bordered_block = [&](int64_t o, const T* Pc, hipStream_t s, int64_t c0, int64_t nc, int64_t r0, int64_t nr) {
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    const int64_t t0 = o + nbp, ntrail = n - t0;
+    if (nr <= 0 || nc <= 0) return;
+    launch_gemm_nt<T>(nr % 128 == 0 && nc % 128 == 0 ? 128 : 64, A + (n + r0) * ld + c0, ld, Pc + (ntrail + r0) * ldp, ldp,
+                      Pc + (c0 - t0) * ldp, ldp, nr, nc, nbp, 0, 0, s);
+  };
   // does a 128-tile trailing update run beside the look-ahead chain of the panel behind offset o?  If not,
   // the chain's small launches are alone on the GPU and take the latency mode of the 64-tile engine.
   auto update_is_big = [&](int64_t o) -> bool {
@@ -448,7 +456,7 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     }
     {
       PhaseScope ps(h, &h->tm.chol_trsm, profile);
-      if ((rc = panel_solve_enqueue(h, A, ld, 0, nb0, n - nb0, nx, Winv, Pbuf[0], ldp, s0, iw, 0))) return rc;
+      if ((rc = panel_solve_enqueue(h, A, ld, 0, nb0, n - nb0 + nxa, nx - nxa, Winv, Pbuf[0], ldp, s0, iw, 0))) return rc;
     }
     if (any_fused) {
       bordered_update(0, Pbuf[0], s0);
@@ -533,12 +541,13 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       // The host enqueues the main stream's whole iteration BEFORE the diagonal chain's ~50 small launches: the
       // GPU runs the chain about as fast as the host can enqueue it (N = 8192: the update used to reach the GPU
       // 0.5 ms after the panel it needs, and then collided with the NEXT panel solve and diagonal-block update).
-      {
+      {  // rows below the diagonal block in the next panel's columns: matrix rows and the first nxa bordered rows
+         // (which lie directly below them, in A and in P) in one launch; the other bordered rows in a small one
         PhaseScope ps(h, &h->tm.chol_strip, profile, sm);
-        if (nrest > 0)
-          launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + t0, ld, Pc + (int64_t)nbn * ldp, ldp, Pc, ldp, nrest, nbn, nbp, 0,
-                            0, sm);
-        bordered_update(o, Pc, sm);
+        if (nrest + nxa > 0)
+          launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + t0, ld, Pc + (int64_t)nbn * ldp, ldp, Pc, ldp, nrest + nxa, nbn,
+                            nbp, 0, 0, sm);
+        bordered_block(o, Pc, sm, t0, nbn, nxa, nx - nxa);
       }
       hipEvent_t e_below = next_event(h);
       if (!e_below) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
@@ -577,6 +586,11 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
         if (!e_main) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
         HIPCHK(h, hipEventRecord(e_main, sm));
       }
+      if (nrest > 0) {  // the bordered rows' share of the REST (columns beyond the next panel)
+        PhaseScope ps(h, &h->tm.chol_strip, profile, sm);
+        bordered_block(o, Pc, sm, t0 + nbn, nrest, 0, nxa);
+        bordered_block(o, Pc, sm, t0 + nbn, nrest, nxa, nx - nxa);
+      }
       {
         PhaseScope ps(h, &h->tm.chol_diag, profile, s1);
         if ((rc = diag_enqueue(h, A, ld, t0, nbn, Winv, info, gidx0, s1, iw))) return rc;
@@ -584,7 +598,8 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       HIPCHK(h, hipStreamWaitEvent(s1, e_below, 0));
       {
         PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
-        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest, nx, Winv, Pn, ldp, s1, iw, (step + 1) & 1))) return rc;
+        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest + nxa, nx - nxa, Winv, Pn, ldp, s1, iw, (step + 1) & 1)))
+          return rc;
       }
       HIPCHK(h, hipEventRecord(e_panel, s1));
       HIPCHK(h, hipStreamWaitEvent(sm, e_panel, 0));
@@ -801,11 +816,16 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
 
 namespace {
 
+// Xq != null (gpx_fit_predict): the M query points' cross-kernel rows K* ride through the factorisation as
+// bordered rows too — directly below the matrix, in front of the right-hand sides — and leave it as
+// V^T = (L^-1 K*^T)^T: the variance solve of predict costs no pass of its own (its M N^2 flops are rows of
+// the trailing updates, which at small N fill the CUs the serial diagonal chain leaves idle).
 template <typename T>
 int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
              const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter,
-             int32_t mem_kind, int64_t* info) {
+             int32_t mem_kind, int64_t* info, const void* Xq = nullptr, int64_t M = 0) {
   const int64_t Npad = round_up(N, TILE);
+  const int64_t Mpad = Xq ? round_up(M, TILE) : 0;
   const int64_t ld = Npad + ld_skew<T>();
   const int64_t ldp = h->nb + ld_skew<T>();
   h->N = N; h->Npad = Npad; h->ld = ld; h->ldp = ldp; h->d = d; h->k = k; h->n_ls = n_ls;
@@ -822,7 +842,11 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   if ((rc = ensure(h, h->Y, (size_t)N * k * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->Xs, (size_t)Npad * d * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->ls, 32 * 8))) return rc;
-  const int64_t NX = RHS_ROWS;  // bordered rows: the right-hand sides ride through the factorisation
+  const int64_t NX = RHS_ROWS + Mpad;  // bordered rows: [K* rows of a fused predict] + the right-hand sides
+  if (Xq) {
+    if ((rc = ensure(h, h->Q, (size_t)M * d * sizeof(T)))) return rc;
+    if ((rc = ensure(h, h->Qs, (size_t)Mpad * d * sizeof(T)))) return rc;
+  }
   if ((rc = ensure(h, h->K, (size_t)(Npad + NX) * ld * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->Winv, (size_t)(Npad / KB) * KB * KB * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->P, (size_t)2 * (Npad + NX) * ldp * sizeof(T)))) return rc;
@@ -843,7 +867,7 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   T* dK = (T*)h->K.p;
   h->Lfac = dK;
   h->repl = false;
-  T* dYT = dK + Npad * ld;  // rows [Npad, Npad + NX) of the K buffer: y^T, then z^T = (L^-1 y)^T
+  T* dYT = dK + (Npad + Mpad) * ld;  // the last RHS_ROWS rows of the K buffer: y^T, then z^T = (L^-1 y)^T
   h->zT = dYT;
   h->alphaT = nullptr;
   h->alpha_ready = false;
@@ -864,12 +888,18 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
                           (T*)h->Xs.p, h->st);
       launch_kbuild_sym<T>(h->cfg.kernel, (const T*)h->Xs.p, N, Npad, d, sf2, sn2 + jitter, dK, ld,
                         h->st);
+      if (Xq) {  // rows [Npad, Npad + Mpad): K(Xq, X)
+        if ((rc = copy_in(h, h->Q.p, Xq, (size_t)M * d * sizeof(T), mem_kind))) return rc;
+        launch_scale_points<T>((const T*)h->Q.p, M, Mpad, d, (const double*)h->ls.p, n_ls, (T*)h->Qs.p, h->st);
+        launch_kbuild_cross<T>(h->cfg.kernel, (const T*)h->Qs.p, M, Mpad, (const T*)h->Xs.p, N, Npad, d, sf2,
+                            dK + Npad * ld, ld, h->st);
+      }
     }
     {
       PhaseScope ps(h, &tm.chol);
-      launch_pack_rhs<T>((const T*)h->Y.p, N, k, dYT, ld, Npad, (int)NX, h->st);
+      launch_pack_rhs<T>((const T*)h->Y.p, N, k, dYT, ld, Npad, RHS_ROWS, h->st);
       if ((rc = chol_enqueue<T>(h, dK, ld, Npad, h->nb, (T*)h->Winv.p, (T*)h->P.p,
-                                (T*)h->P.p + (Npad + NX) * ldp, ldp, dInfo, 0, profile, NX, &iw)))
+                                (T*)h->P.p + (Npad + NX) * ldp, ldp, dInfo, 0, profile, NX, &iw, Mpad)))
         return rc;
     }
     // The forward substitution happened inside the factorisation (bordered rows).  The
@@ -997,6 +1027,48 @@ int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var
   {
     PhaseScope total(h, &tm.predict_total);
     if ((rc = predict_core<T>(h, Xq, M, var != nullptr, mem_kind))) return rc;
+    PhaseScope ps(h, &tm.d2h);
+    if ((rc = copy_out(h, mean, h->meanout.p, (size_t)M * h->k * sizeof(T), mem_kind))) return rc;
+    if (var && (rc = copy_out(h, var, h->var.p, (size_t)M * sizeof(T), mem_kind))) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->st));
+  HIPCHK(h, hipGetLastError());
+  LAUNCHCHK(h);
+  collect_phases(h);
+  return GPX_OK;
+}
+
+// The predict half of gpx_fit_predict: V^T already sits in rows [Npad, Npad + Mpad) of the factor's buffer
+// (fit_impl with query points); what is left is the mean V^T z and the row norms.
+template <typename T>
+int fused_predict_tail(gpx_handle* h, int64_t M, void* mean, void* var, int32_t mem_kind) {
+  const int64_t Npad = h->Npad, ld = h->ld;
+  const int64_t Mpad = round_up(M, TILE), ldm = Mpad + ld_skew<T>();
+  gpx_timings& tm = h->tm;
+  tm.kstar = tm.mean = tm.trsm = tm.var = tm.d2h = tm.predict_total = 0;
+  int rc;
+  if ((rc = ensure(h, h->MT, (size_t)RHS_ROWS * ldm * sizeof(T)))) return rc;
+  const int ksplit = splitk_splits(Npad);
+  const int64_t ldpm = Mpad + ld_skew<T>();
+  if (ksplit > 1 && (rc = ensure(h, h->MTpart, (size_t)ksplit * RHS_ROWS * ldpm * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->meanout, (size_t)M * h->k * sizeof(T)))) return rc;
+  if ((rc = ensure(h, h->var, (size_t)Mpad * sizeof(T)))) return rc;
+  const T* dVT = (const T*)h->Lfac + Npad * ld;
+  {
+    PhaseScope total(h, &tm.predict_total);
+    {
+      PhaseScope ps(h, &tm.mean);
+      if (ksplit > 1)
+        launch_gemm_nt_splitk<T>((T*)h->MT.p, ldm, (const T*)h->zT, ld, dVT, ld, RHS_ROWS, Mpad, Npad, ksplit,
+                                 (T*)h->MTpart.p, ldpm, h->st);
+      else
+        launch_gemm_nt<T>(64, (T*)h->MT.p, ldm, (const T*)h->zT, ld, dVT, ld, RHS_ROWS, Mpad, Npad, 0, 1, h->st);
+      launch_unpack_rhs<T>((const T*)h->MT.p, ldm, M, h->k, 1.0, (T*)h->meanout.p, h->st);
+    }
+    if (var) {
+      PhaseScope ps(h, &tm.var);
+      launch_var_rows<T>(dVT, ld, M, Npad, h->sf2, (T*)h->var.p, h->st);
+    }
     PhaseScope ps(h, &tm.d2h);
     if ((rc = copy_out(h, mean, h->meanout.p, (size_t)M * h->k * sizeof(T), mem_kind))) return rc;
     if (var && (rc = copy_out(h, var, h->var.p, (size_t)M * sizeof(T), mem_kind))) return rc;
@@ -1460,6 +1532,39 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
   if (h->cfg.dtype == GPX_F32)
     return fit_impl<float>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
   return fit_impl<double>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
+}
+GPX_CATCH_ALL
+
+int gpx_fit_predict(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
+                    const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter, const void* Xq,
+                    int64_t M, void* mean, void* var, int32_t mem_kind, int64_t* info) try {
+  if (!h) return GPX_E_ARG;
+  if (!X || !y || !lengthscale || !info || !Xq || !mean) return fail(h, GPX_E_ARG, "gpx_fit_predict: null argument");
+  if (N <= 0 || d <= 0 || d > 32 || M <= 0) return fail(h, GPX_E_ARG, "gpx_fit_predict: need N, M > 0 and 1 <= d <= 32");
+  if (k <= 0 || k > RHS_ROWS) return fail(h, GPX_E_ARG, "gpx_fit_predict: need 1 <= k <= 64 target columns");
+  if (n_ls != 1 && n_ls != d) return fail(h, GPX_E_ARG, "gpx_fit_predict: n_ls must be 1 or d");
+  if (mem_kind != GPX_MEM_HOST && mem_kind != GPX_MEM_DEVICE) return fail(h, GPX_E_ARG, "gpx_fit_predict: bad mem_kind");
+  if (!(sf2 > 0.0) || sn2 < 0.0 || jitter < 0.0)
+    return fail(h, GPX_E_ARG, "gpx_fit_predict: need sf2 > 0, sn2 >= 0, jitter >= 0");
+  for (int i = 0; i < n_ls; ++i)
+    if (!(lengthscale[i] > 0.0)) return fail(h, GPX_E_ARG, "gpx_fit_predict: lengthscale must be > 0");
+  if (N > (int64_t)INT_MAX - 4096) return fail(h, GPX_E_ARG, "gpx_fit_predict: N too large");
+  // one device, one precision: groups, shards and the mixed mode factor and predict in separate calls
+  if (h->group || h->cfg.world > 1 || h->comm || h->cfg.dtype == GPX_MIXED)
+    return fail(h, GPX_E_UNSUPPORTED, "gpx_fit_predict: single-device fp64 / fp32 handles only (use gpx_fit + gpx_predict)");
+  if (M > pred_batch_rows(h, round_up(M, TILE), 0, false))
+    return fail(h, GPX_E_UNSUPPORTED, "gpx_fit_predict: more query points than one predict batch (use gpx_fit + gpx_predict)");
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  h->fitted = false;
+  h->err.clear();
+  h->phases.clear();
+  h->ev_used = 0;
+  int rc = h->cfg.dtype == GPX_F32
+               ? fit_impl<float>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info, Xq, M)
+               : fit_impl<double>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info, Xq, M);
+  if (rc != GPX_OK || !h->fitted) return rc;  // *info > 0: not positive definite, nothing predicted
+  return h->cfg.dtype == GPX_F32 ? fused_predict_tail<float>(h, M, mean, var, mem_kind)
+                                 : fused_predict_tail<double>(h, M, mean, var, mem_kind);
 }
 GPX_CATCH_ALL
 

@@ -123,7 +123,8 @@ class GP:
         self.info_ = 0
         self.jitter_used_ = self.jitter
         self._host_comm = None
-        if self.world > 1 or comm is not None:
+        self._has_comm = self.world > 1 or comm is not None
+        if self._has_comm:
             self._init_comm(comm, group)
 
     def _resolve_devices(self, devices, oversubscribe):
@@ -245,6 +246,69 @@ class GP:
         self._check(self._lib.gpx_logdet(self._h, C.byref(ld)))
         self.log_det_ = float(ld.value)
         return self
+
+    def fit_predict(self, X, y, Xs, include_noise=False):
+        """``fit(X, y)`` and ``predict(Xs)`` (mean and variance) as ONE factorisation pass: the cross-kernel rows
+        of the query points ride through the blocked Cholesky as bordered rows (``gpx_fit_predict``), so the
+        variance solve is part of the trailing updates instead of a pass of its own — the small-N schedule
+        (N = 8192: the updates' idle CUs take the work).  The model is fitted afterwards as after ``fit``.
+        Groups, shards, ``dtype="mixed"`` and more query points than one predict batch take the two calls."""
+        fused = not self._is_group and not self._has_comm and self.dtype in ("float64", "float32")
+        pq, kq, keepq, devq, sq = self._as_input(Xs, "Xs")
+        px, kx, keepx, devx, sx = self._as_input(X, "X")
+        py, ky, keepy, devy, sy = self._as_input(y, "y")
+        if not fused or len(sq) != 2 or sq[0] > 8192 or not (kx == ky == kq):
+            mean, var = self.fit(X, y).predict(Xs, include_noise=include_noise)
+            return mean, var
+        if len(sx) != 2:
+            raise ValueError("X must be (N, d)")
+        N, d = sx
+        if len(sy) not in (1, 2) or sy[0] != N:
+            raise ValueError("y must be (N,) or (N, k) with the same N as X")
+        if sq[1] != d:
+            raise ValueError(f"Xs must be (M, {d})")
+        k = 1 if len(sy) == 1 else sy[1]
+        if self.lengthscale.size not in (1, d):
+            raise ValueError("lengthscale must be scalar or have d entries")
+        M = sq[0]
+        self._y1d = len(sy) == 1
+        self._N, self._d, self._k = N, d, k
+        self._alpha = None
+        self._fitted = False
+        mshape = (M,) if self._y1d else (M, k)
+        if devq is not None:
+            import torch
+            tdt = torch.float32 if self.dtype == "float32" else torch.float64
+            mean = torch.empty(mshape, dtype=tdt, device=devq)
+            var = torch.empty((M,), dtype=tdt, device=devq)
+            pm, pv = C.c_void_p(mean.data_ptr()), C.c_void_p(var.data_ptr())
+        else:
+            mean = np.empty(mshape, dtype=self._np_dtype)
+            var = np.empty((M,), dtype=self._np_dtype)
+            pm, pv = C.c_void_p(mean.ctypes.data), C.c_void_p(var.ctypes.data)
+        ls = self.lengthscale
+        jitter = self.jitter
+        info = C.c_int64(0)
+        for _ in range(max(1, self.max_tries)):
+            rc = self._lib.gpx_fit_predict(self._h, px, py, N, d, k, _abi.dptr(ls), ls.size, self.variance, self.noise,
+                                           jitter, pq, M, pm, pv, kx, C.byref(info))
+            self._check(rc)
+            self.info_ = int(info.value)
+            if self.info_ == 0:
+                break
+            jitter = max(jitter, 1e-12 * self.variance) * 10.0
+        else:
+            raise np.linalg.LinAlgError(
+                f"kernel matrix not positive definite (first bad pivot {self.info_}) after "
+                f"{self.max_tries} jitter escalations")
+        self.jitter_used_ = jitter
+        self._fitted = True
+        ld = C.c_double(0.0)
+        self._check(self._lib.gpx_logdet(self._h, C.byref(ld)))
+        self.log_det_ = float(ld.value)
+        if include_noise:
+            var += self.noise
+        return mean, var
 
     def predict(self, Xs, return_var=True, include_noise=False):
         if not self._fitted:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GPX_ABI_VERSION 3
+#define GPX_ABI_VERSION 4
 
 /* kernel family — SURVEY.md §8 row a1 (nearest reference code: the pairwise
  * distance loop trajectories.calc_distance, GPmap.py:114-121, and the unused
@@ -127,6 +127,19 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
  * raw — not clamped).  var may be NULL (mean only). */
 int gpx_predict(gpx_handle* h, const void* Xs, int64_t M, void* mean, void* var,
                 int32_t mem_kind);
+
+/* gpx_fit and gpx_predict (with variance) of ONE batch of query points as one call (ABI v4): the M cross-kernel
+ * rows K(Xs, X) ride through the blocked factorisation as bordered rows — the way the right-hand sides already
+ * do — and leave it as V^T = (L^-1 K*^T)^T, so the variance solve costs no pass of its own: its M N^2 flops are
+ * rows of the trailing updates (at small N they run on the CUs the serial diagonal chain leaves idle; N = 8192,
+ * M = 4096: 12.8 -> see DESIGN.md §5.2).  Same results as the two calls up to the rounding of a different
+ * summation order; the handle is fitted afterwards exactly as after gpx_fit (gpx_predict, gpx_get_alpha,
+ * gpx_lml_grad ... work on it).  *info > 0: not positive definite, nothing was predicted.  Single-device
+ * GPX_F64 / GPX_F32 handles and M <= one predict batch (8192 rows); otherwise GPX_E_UNSUPPORTED — call
+ * gpx_fit + gpx_predict.  Mirrors the reference-side usage `gp.fit(X, y); gp.predict(Xs)`. */
+int gpx_fit_predict(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
+                    const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter, const void* Xs,
+                    int64_t M, void* mean, void* var /* may be NULL */, int32_t mem_kind, int64_t* info);
 
 int gpx_get_alpha(gpx_handle* h, void* out /* (N,k) host */);
 /* Log marginal likelihood of the last fit and its gradient w.r.t. the LOG hyper-parameters —
