@@ -395,7 +395,7 @@ int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int
 template <typename T>
 int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T* P0, T* P1,
                  int64_t ldp, int* info, int64_t gidx0, bool profile, int64_t nx = 0,
-                 InvWork<T>* iw = nullptr, int64_t nxa = 0) {
+                 InvWork<T>* iw = nullptr, int64_t nx_side = 0) {
   hipStream_t s0 = h->st, s1 = h->st2;
   T* Pbuf[2] = {P0, P1};
   int rc;
@@ -443,6 +443,35 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     const int64_t nrest = ntrail - nbn;
     return nrest > 0 && ntrail % 128 == 0 && nbn % 128 == 0 && gemm_nt_tile(128, nrest, nrest, 1) == 128;
   };
+  const bool split_env = [] {  // read per call (tests switch it)
+    const char* e = getenv("GPX_SPLIT_STRIP");
+    return !e || atoi(e) != 0;
+  }() && !fuse_env;  // (the fused update keeps its own hand-over)
+  const int rest_split = [] {  // trailing rows (in panels) up to which the REST hands its first column block over early
+    const char* e = getenv("GPX_REST_SPLIT");
+    return e ? atoi(e) : 16;
+  }();
+  // The LAST nx_side bordered rows (the query points of gpx_fit_predict: a multiple of 128) are the main stream's
+  // business alone in the split schedule: their panel solves, like their updates, are throughput work no step of the
+  // chain waits for (tried: a stream of their own that trails the factorisation panel by panel, reading L from A —
+  // slower, N = 8192: 12.4 against 11.6 ms; one more stream's worth of serial block solves).  The other bordered
+  // rows (the right-hand sides) ride in the chain's panel solves as before.
+  const int64_t nxs = split_env ? nx_side : 0, nxc = nx - nxs;
+  auto side_solve = [&](int64_t o, T* Pp, hipStream_t s) -> int {  // side rows of the panel at offset o -> P and back into A
+    if (nxs <= 0) return GPX_OK;
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    T* Aside = A + (n + nxc) * ld + o;
+    T* Pside = Pp + ((n - o - nbp) + nxc) * ldp;
+    if (!iw) {
+      launch_trsm_rlt<T>(Aside, ld, nxs, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, Pside, ldp, s);
+      return GPX_OK;
+    }
+    HIPCHK(h, hipStreamWaitEvent(s, iw->ready, 0));
+    launch_gemm_nt<T>(nxs % 128 == 0 && nbp % 128 == 0 ? 128 : 64, Pside, ldp, Aside, ld,
+                      iw->W + (o / iw->nbw) * (int64_t)iw->nbw * iw->nbw, iw->nbw, nxs, nbp, nbp, 4, 1, s);
+    launch_copy2d<T>(Aside, ld, Pside, ldp, nxs, nbp, s);
+    return GPX_OK;
+  };
   LatencyGuard latency_guard;
   set_latency_mode(1);  // panel 0: nothing runs beside it
   const bool any_fused = is_fused(0);
@@ -456,7 +485,7 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     }
     {
       PhaseScope ps(h, &h->tm.chol_trsm, profile);
-      if ((rc = panel_solve_enqueue(h, A, ld, 0, nb0, n - nb0 + nxa, nx - nxa, Winv, Pbuf[0], ldp, s0, iw, 0))) return rc;
+      if ((rc = panel_solve_enqueue(h, A, ld, 0, nb0, n - nb0, nxc, Winv, Pbuf[0], ldp, s0, iw, 0))) return rc;
     }
     if (any_fused) {
       bordered_update(0, Pbuf[0], s0);
@@ -466,14 +495,6 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       HIPCHK(h, hipStreamWaitEvent(s1, e_init, 0));  // counter reset + panel 0 before the parked stream's first poll
     }
   }
-  const bool split_env = [] {  // read per call (tests switch it)
-    const char* e = getenv("GPX_SPLIT_STRIP");
-    return !e || atoi(e) != 0;
-  }() && !fuse_env;  // (the fused update keeps its own hand-over)
-  const int rest_split = [] {  // trailing rows (in panels) up to which the REST hands its first column block over early
-    const char* e = getenv("GPX_REST_SPLIT");
-    return e ? atoi(e) : 16;
-  }();
   hipStream_t cur_main = s0;
   hipEvent_t e_main = nullptr;  // split strip: "the main stream's work on the trailing matrix so far is complete"
   if (split_env && n > nb) {
@@ -486,7 +507,10 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     const int nbp = (int)std::min<int64_t>(nb, n - o);
     const int64_t t0 = o + nbp;          // first trailing row/col
     const int64_t ntrail = n - t0;
-    if (ntrail <= 0) break;
+    if (ntrail <= 0) {  // the last panel: nothing to update, but the side rows still take their solve
+      if ((rc = side_solve(o, Pbuf[step & 1], cur_main))) return rc;
+      break;
+    }
     T* Pc = Pbuf[step & 1];              // panel of this step, rows [t0, n + nx)
     T* Pn = Pbuf[(step + 1) & 1];
     const int nbn = (int)std::min<int64_t>(nb, ntrail);  // width of the next panel
@@ -541,13 +565,12 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       // The host enqueues the main stream's whole iteration BEFORE the diagonal chain's ~50 small launches: the
       // GPU runs the chain about as fast as the host can enqueue it (N = 8192: the update used to reach the GPU
       // 0.5 ms after the panel it needs, and then collided with the NEXT panel solve and diagonal-block update).
-      {  // rows below the diagonal block in the next panel's columns: matrix rows and the first nxa bordered rows
-         // (which lie directly below them, in A and in P) in one launch; the other bordered rows in a small one
+      {  // rows below the diagonal block in the next panel's columns; the chain's bordered rows in a small launch
         PhaseScope ps(h, &h->tm.chol_strip, profile, sm);
-        if (nrest + nxa > 0)
-          launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + t0, ld, Pc + (int64_t)nbn * ldp, ldp, Pc, ldp, nrest + nxa, nbn,
-                            nbp, 0, 0, sm);
-        bordered_block(o, Pc, sm, t0, nbn, nxa, nx - nxa);
+        if (nrest > 0)
+          launch_gemm_nt<T>(tile, A + (t0 + nbn) * ld + t0, ld, Pc + (int64_t)nbn * ldp, ldp, Pc, ldp, nrest, nbn, nbp, 0,
+                            0, sm);
+        bordered_block(o, Pc, sm, t0, nbn, 0, nxc);
       }
       hipEvent_t e_below = next_event(h);
       if (!e_below) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
@@ -586,10 +609,12 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
         if (!e_main) return fail(h, GPX_E_HIP, "hipEventCreate failed (look-ahead)");
         HIPCHK(h, hipEventRecord(e_main, sm));
       }
-      if (nrest > 0) {  // the bordered rows' share of the REST (columns beyond the next panel)
+      {  // the bordered rows' share of the REST (columns beyond the next panel); the side rows' whole step — their
+         // panel solve and the update of every column to the right — behind everything the chain waits for
         PhaseScope ps(h, &h->tm.chol_strip, profile, sm);
-        bordered_block(o, Pc, sm, t0 + nbn, nrest, 0, nxa);
-        bordered_block(o, Pc, sm, t0 + nbn, nrest, nxa, nx - nxa);
+        bordered_block(o, Pc, sm, t0 + nbn, nrest, 0, nxc);
+        if ((rc = side_solve(o, Pc, sm))) return rc;
+        bordered_block(o, Pc, sm, t0, ntrail, nxc, nxs);
       }
       {
         PhaseScope ps(h, &h->tm.chol_diag, profile, s1);
@@ -598,8 +623,7 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       HIPCHK(h, hipStreamWaitEvent(s1, e_below, 0));
       {
         PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
-        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest + nxa, nx - nxa, Winv, Pn, ldp, s1, iw, (step + 1) & 1)))
-          return rc;
+        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest, nxc, Winv, Pn, ldp, s1, iw, (step + 1) & 1))) return rc;
       }
       HIPCHK(h, hipEventRecord(e_panel, s1));
       HIPCHK(h, hipStreamWaitEvent(sm, e_panel, 0));
@@ -817,7 +841,7 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
 namespace {
 
 // Xq != null (gpx_fit_predict): the M query points' cross-kernel rows K* ride through the factorisation as
-// bordered rows too — directly below the matrix, in front of the right-hand sides — and leave it as
+// bordered rows too — below the right-hand sides — and leave it as
 // V^T = (L^-1 K*^T)^T: the variance solve of predict costs no pass of its own (its M N^2 flops are rows of
 // the trailing updates, which at small N fill the CUs the serial diagonal chain leaves idle).
 template <typename T>
@@ -867,7 +891,7 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   T* dK = (T*)h->K.p;
   h->Lfac = dK;
   h->repl = false;
-  T* dYT = dK + (Npad + Mpad) * ld;  // the last RHS_ROWS rows of the K buffer: y^T, then z^T = (L^-1 y)^T
+  T* dYT = dK + Npad * ld;  // rows [Npad, Npad + RHS_ROWS) of the K buffer: y^T, then z^T = (L^-1 y)^T
   h->zT = dYT;
   h->alphaT = nullptr;
   h->alpha_ready = false;
@@ -888,11 +912,11 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
                           (T*)h->Xs.p, h->st);
       launch_kbuild_sym<T>(h->cfg.kernel, (const T*)h->Xs.p, N, Npad, d, sf2, sn2 + jitter, dK, ld,
                         h->st);
-      if (Xq) {  // rows [Npad, Npad + Mpad): K(Xq, X)
+      if (Xq) {  // rows [Npad + RHS_ROWS, ... + Mpad): K(Xq, X)
         if ((rc = copy_in(h, h->Q.p, Xq, (size_t)M * d * sizeof(T), mem_kind))) return rc;
         launch_scale_points<T>((const T*)h->Q.p, M, Mpad, d, (const double*)h->ls.p, n_ls, (T*)h->Qs.p, h->st);
         launch_kbuild_cross<T>(h->cfg.kernel, (const T*)h->Qs.p, M, Mpad, (const T*)h->Xs.p, N, Npad, d, sf2,
-                            dK + Npad * ld, ld, h->st);
+                            dK + (Npad + RHS_ROWS) * ld, ld, h->st);
       }
     }
     {
@@ -1038,7 +1062,7 @@ int predict_impl(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var
   return GPX_OK;
 }
 
-// The predict half of gpx_fit_predict: V^T already sits in rows [Npad, Npad + Mpad) of the factor's buffer
+// The predict half of gpx_fit_predict: V^T already sits in the Mpad rows below the right-hand sides in the factor's buffer
 // (fit_impl with query points); what is left is the mean V^T z and the row norms.
 template <typename T>
 int fused_predict_tail(gpx_handle* h, int64_t M, void* mean, void* var, int32_t mem_kind) {
@@ -1053,7 +1077,7 @@ int fused_predict_tail(gpx_handle* h, int64_t M, void* mean, void* var, int32_t 
   if (ksplit > 1 && (rc = ensure(h, h->MTpart, (size_t)ksplit * RHS_ROWS * ldpm * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->meanout, (size_t)M * h->k * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->var, (size_t)Mpad * sizeof(T)))) return rc;
-  const T* dVT = (const T*)h->Lfac + Npad * ld;
+  const T* dVT = (const T*)h->Lfac + (Npad + RHS_ROWS) * ld;
   {
     PhaseScope total(h, &tm.predict_total);
     {
