@@ -468,6 +468,7 @@ def run(args):
     ok = True if gp is None else bool(torch.isfinite(mean).all().item() and (var > (0 if dtype == "float64" else -1e-4)).all().item())
     pcie_ms = None
     unprofiled_ms = None
+    one_pass = None
     if world == 1 and not shard:
         # the same step with HOST NumPy arrays in and out (H2D of X, y, Xs and D2H of mean, var inside
         # the clock): never `value`, stated once beside it
@@ -490,6 +491,22 @@ def run(args):
                 else:
                     t_plain += time.perf_counter() - t1
         unprofiled_ms = (t_plain * 1e3 / nrep, t_prof * 1e3 / nrep)
+        # the ONE-PASS form of the same step (GP.fit_predict -> gpx_fit_predict, ABI v4: the query points' cross-kernel
+        # rows ride through the factorisation as bordered rows): reported beside the headline, never `value`
+        one_pass = None
+        if dtype in ("float64", "float32") and M <= 8192:
+            gp.fit_predict(Xd, yd, Xsd)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(nrep):
+                m1p, v1p = gp.fit_predict(Xd, yd, Xsd)
+            torch.cuda.synchronize(dev)
+            ms1 = (time.perf_counter() - t1) * 1e3 / nrep
+            one_pass = {"ms_per_step": ms1, "points_per_s": (N + M) / (ms1 * 1e-3),
+                        "mean_max_abs_diff_vs_two_calls": float((m1p - mean).abs().max().item()),
+                        "var_max_abs_diff_vs_two_calls": float((v1p - var).abs().max().item()),
+                        "note": "gp.fit_predict(X, y, Xs): same inputs, same outputs, one factorisation pass"}
+            del m1p, v1p
     shard_check = None
     if shard and N <= 131072:
         # the sharded posterior against the single-GPU path on the same inputs (rank 0's GPU)
@@ -536,6 +553,7 @@ def run(args):
                 "note": "the timed steps run with GPX_FLAG_PROFILE (hipEvent pairs around the Cholesky sub-phase launches: "
                         "the roofline's clock); measured after the timed region on the same handle, flag toggled step by "
                         "step (without, with, without, ...), so that buffers and clock drift are the same"},
+            "fit_predict_one_pass": one_pass,
             "higher_is_better": True,
             "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": {"float64": "f64", "float32": "f32", "mixed": "f32 factor + f64 refinement"}[dtype],
