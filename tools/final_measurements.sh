@@ -23,6 +23,11 @@ find $O -name "*counter_collection.csv" -delete
 find $O -name "*kernel_trace.csv" -delete
 python bench.py > $O/bench.json 2> $O/bench.err
 python tools/c2_bench.py > $O/c2_bench.json 2> $O/c2_bench.err
+python tools/c2_bench.py --no-profile > $O/c2_bench_noprofile.json 2>> $O/c2_bench.err
+python tools/c2_bench.py --no-profile --fused > $O/c2_bench_one_pass.json 2>> $O/c2_bench.err
+GPX_SPLIT_STRIP=0 python tools/c2_bench.py --no-profile > $O/c2_bench_unsplit.json 2>> $O/c2_bench.err
+GPX_SPLIT_STRIP=0 python bench.py --no-cpu-baseline --no-microbench > $O/bench_unsplit.json 2> $O/bench_unsplit.err
+export C2_ARGS=--no-profile GAPS_ARGS=--main; bash tools/r03_c2trace.sh > /dev/null 2>&1; cp gpurun_out/r03_c2_chain_gaps.txt $O/c2_chain_gaps.txt
 GPX_FUSED_STRIP=1 python bench.py --no-cpu-baseline --no-microbench > $O/bench_fused.json 2> $O/bench_fused.err
 ls -la $O $O/stats/* | head -40
 tail -c 400 $O/bench.json
