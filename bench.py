@@ -39,6 +39,9 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                  summed over the launches of that kernel in the timed steps (library events
                  on the library's stream, GPX_FLAG_PROFILE; the last few, under-filled
                  updates of a fit run as 64-tiles — another kernel — and are not counted)
+  fit_predict_one_pass — the same step as ONE call (``gp.fit_predict`` -> gpx_fit_predict, ABI v4: the query rows ride
+                 through the factorisation), a few steps after the timed region; reported beside the headline,
+                 never ``value``
   cpu_baseline — the NumPy/SciPy oracle (oracle/gp_oracle.py) on the GPU box's host cores.
                  ``value`` is the rate AT THE WORKLOAD (N=65536): the full-size oracle run that
                  also wrote the committed golden fixture (oracle/make_golden_full.py, ~2 min with 16
