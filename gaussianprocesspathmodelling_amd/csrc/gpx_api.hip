@@ -344,19 +344,33 @@ int diag_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, T* Winv, i
 // stored back into A.  With the block inverse: two dense products (main rows / bordered rows) into
 // P on stream s, and the copy back into A on the auxiliary stream (nobody reads the panel from A
 // before the factorisation is over: the trailing updates read P).  Without: the slab kernel.
+// row0 / prev / last (round 3): the rows [row0, row0 + rows_main + nx) of the panel only — the split schedule solves
+// the rows of the next diagonal block on the chain and the rest on the main stream.  `prev` is the copy-back event
+// of the panel that last lived in P[set] (every part waits for it before it writes); the part with `last` set
+// records the new one (both parts' copies run in order on the copy stream).
 template <typename T>
 int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int64_t rows_main, int64_t nx,
-                        const T* Winv, T* P, int64_t ldp, hipStream_t s, InvWork<T>* iw, int set) {
-  T* Apanel = A + (o + nbp) * ld + o;
+                        const T* Winv, T* P, int64_t ldp, hipStream_t s, InvWork<T>* iw, int set, int64_t row0 = 0,
+                        hipEvent_t prev = nullptr, bool last = true) {
+  T* Apanel = A + (o + nbp + row0) * ld + o;
+  P += row0 * ldp;
   const int64_t rows = rows_main + nx;
-  if (rows <= 0) return GPX_OK;
+  if (rows <= 0) {
+    if (iw && last && row0 > 0) {  // nothing in this part: the first part's copy is the panel's
+      iw->copied[set] = next_event(h);
+      if (!iw->copied[set]) return fail(h, GPX_E_HIP, "hipEventCreate failed (panel copy)");
+      HIPCHK(h, hipEventRecord(iw->copied[set], h->st4));
+    }
+    return GPX_OK;
+  }
   if (!iw) {
     launch_trsm_rlt<T>(Apanel, ld, rows, A + o * ld + o, ld, Winv + (o / KB) * (KB * KB), nbp, P, ldp, s);
     return GPX_OK;
   }
   const T* Wp = iw->W + (o / iw->nbw) * (int64_t)iw->nbw * iw->nbw;
   HIPCHK(h, hipStreamWaitEvent(s, iw->ready, 0));
-  if (iw->copied[set]) HIPCHK(h, hipStreamWaitEvent(s, iw->copied[set], 0));  // P[set] is about to be overwritten
+  if (row0 == 0 && last) prev = iw->copied[set];
+  if (prev) HIPCHK(h, hipStreamWaitEvent(s, prev, 0));  // P[set] is about to be overwritten
   const int tile_main = gemm_nt_tile((rows_main % 128 == 0 && nbp % 128 == 0) ? 128 : 64, rows_main, nbp, 4);
   if (rows_main > 0 && nx > 0 && tile_main == 64) {
     // the bordered rows lie directly below the matrix rows, in A and in P: with 64-tiles on both, ONE launch
@@ -373,9 +387,11 @@ int panel_solve_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t o, int nbp, int
   HIPCHK(h, hipEventRecord(e, s));
   HIPCHK(h, hipStreamWaitEvent(h->st4, e, 0));
   launch_copy2d<T>(Apanel, ld, P, ldp, rows, nbp, h->st4);
-  iw->copied[set] = next_event(h);
-  if (!iw->copied[set]) return fail(h, GPX_E_HIP, "hipEventCreate failed (panel copy)");
-  HIPCHK(h, hipEventRecord(iw->copied[set], h->st4));
+  if (last) {
+    iw->copied[set] = next_event(h);
+    if (!iw->copied[set]) return fail(h, GPX_E_HIP, "hipEventCreate failed (panel copy)");
+    HIPCHK(h, hipEventRecord(iw->copied[set], h->st4));
+  }
   return GPX_OK;
 }
 
@@ -447,6 +463,10 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     const char* e = getenv("GPX_SPLIT_STRIP");
     return !e || atoi(e) != 0;
   }() && !fuse_env;  // (the fused update keeps its own hand-over)
+  const bool top_env = [] {  // GPX_SOLVE_TOP=0: the whole panel solve on the chain (A/B)
+    const char* e = getenv("GPX_SOLVE_TOP");
+    return !e || atoi(e) != 0;
+  }();
   const int rest_split = [] {  // trailing rows (in panels) up to which the REST hands its first column block over early
     const char* e = getenv("GPX_REST_SPLIT");
     return e ? atoi(e) : 16;
@@ -621,12 +641,29 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
         if ((rc = diag_enqueue(h, A, ld, t0, nbn, Winv, info, gidx0, s1, iw))) return rc;
       }
       HIPCHK(h, hipStreamWaitEvent(s1, e_below, 0));
+      // Panel solve p+1: only the rows of the NEXT diagonal block (what STRIP_D(p+1) and the B operands need) on the
+      // chain; the rows below them, and the chain's bordered rows, on the main stream in front of its next update
+      // (their inputs are the main stream's own work plus W_{p+1}) — with the block inverse only.
+      const int64_t top = (iw && top_env) ? std::min<int64_t>(nrest, nb) : nrest;
+      hipEvent_t prev_copied = iw ? iw->copied[(step + 1) & 1] : nullptr;
       {
         PhaseScope ps(h, &h->tm.chol_trsm, profile, s1);
-        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest, nxc, Winv, Pn, ldp, s1, iw, (step + 1) & 1))) return rc;
+        if (top < nrest || (iw && top_env)) {
+          if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, top, 0, Winv, Pn, ldp, s1, iw, (step + 1) & 1, 0, prev_copied,
+                                        false)))
+            return rc;
+        } else if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest, nxc, Winv, Pn, ldp, s1, iw, (step + 1) & 1))) {
+          return rc;
+        }
       }
       HIPCHK(h, hipEventRecord(e_panel, s1));
       HIPCHK(h, hipStreamWaitEvent(sm, e_panel, 0));
+      if (top < nrest || (iw && top_env)) {
+        PhaseScope ps(h, &h->tm.chol_trsm, profile, sm);
+        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest - top, nxc, Winv, Pn, ldp, sm, iw, (step + 1) & 1, top,
+                                      prev_copied, true)))
+          return rc;
+      }
       continue;
     }
     {  // STRIP: rows [t0, n) x cols [t0, t0+nbn), tiles on/below the diagonal

@@ -350,7 +350,7 @@ def test_hyperparameter_optimisation_climbs_the_marginal_likelihood():
                                  {"GPX_FUSED_STRIP": "1", "GPX_DIAG_STEP": "64"}, {"GPX_SYRK_W8": "1"},
                                  {"GPX_CHAIN_FLAG": "0"},
                                  {"GPX_SPLIT_STRIP": "0"}, {"GPX_SPLIT_STRIP": "0", "GPX_CHAIN_FLAG": "0"},
-                                 {"GPX_REST_SPLIT": "0"}, {"GPX_REST_SPLIT": "4"}])
+                                 {"GPX_REST_SPLIT": "0"}, {"GPX_REST_SPLIT": "4"}, {"GPX_SOLVE_TOP": "0"}])
 def test_schedule_variants_give_the_same_factorisation(monkeypatch, env):
     """Round-3 schedule switches of the blocked Cholesky: the fused trailing update (strip + rest in ONE
     launch, device-counter hand-over to the look-ahead stream: gemm_nt_fused_kernel / wait_counter_kernel)

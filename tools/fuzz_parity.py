@@ -43,7 +43,7 @@ def one_case(rng, c):
     # round-3 schedule switches, at random: 64-wide diagonal steps, hipEvent hand-over of the diagonal chain
     variant = {"GPX_DIAG_STEP": str(rng.choice(["128", "64"])), "GPX_CHAIN_FLAG": str(rng.choice(["1", "0"])),
                "GPX_SPLIT_STRIP": str(rng.choice(["1", "0"])),
-               "GPX_REST_SPLIT": str(rng.choice(["16", "0", "2"]))}
+               "GPX_REST_SPLIT": str(rng.choice(["16", "0", "2"])), "GPX_SOLVE_TOP": str(rng.choice(["1", "0"]))}
     os.environ.update(variant)
     tag += f" step={variant['GPX_DIAG_STEP']} flag={variant['GPX_CHAIN_FLAG']} split={variant['GPX_SPLIT_STRIP']}"
     if ndev > 1:
@@ -71,6 +71,7 @@ def one_case(rng, c):
         os.environ.pop("GPX_CHAIN_FLAG", None)
         os.environ.pop("GPX_SPLIT_STRIP", None)
         os.environ.pop("GPX_REST_SPLIT", None)
+        os.environ.pop("GPX_SOLVE_TOP", None)
         os.environ.pop("GPX_SHARD_REPLICATE", None)
         os.environ.pop("GPX_NB_SHARD", None)
     return tag, e
