@@ -59,6 +59,24 @@ def test_unsplit_strip_does_not_depend_on_stream_timing(monkeypatch, delay):
     run_delay_case(monkeypatch, delay, 9000, 300, {}, False, False)
 
 
+def test_one_pass_fit_predict_does_not_depend_on_stream_timing(delay):
+    """gpx_fit_predict: the query rows are more work on the main stream between the chain's events (their panel solves,
+    their updates; the split panel solve writes one panel buffer from two streams): 9 panels, M = 700 query points,
+    random delays in front of a third of all launches, five seeds, bit-identical — and equal to the two calls."""
+    X, y, Xs = synthetic_problem(9000, 3, 700, seed=77)
+    with GP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0) as gp:
+        m2, v2 = gp.fit(X, y).predict(Xs)
+        base = gp.fit_predict(X, y, Xs)
+        a0, ld0 = gp.alpha_.copy(), gp.log_det_
+        assert np.max(np.abs(base[0] - m2)) <= 1e-9 * np.max(np.abs(m2)) and np.max(np.abs(base[1] - v2)) <= 1e-9 * 1.5
+        for seed in (1, 7, 123456789, 2024, 99):
+            delay(seed)
+            mean, var = gp.fit_predict(X, y, Xs)
+            delay(0)
+            assert np.array_equal(mean, base[0]) and np.array_equal(var, base[1]), f"seed {seed}"
+            assert np.array_equal(gp.alpha_, a0) and gp.log_det_ == ld0, f"seed {seed}"
+
+
 def run_delay_case(monkeypatch, delay, N, M, kw, grad, small):
     if small:
         monkeypatch.setenv("GPX_NB_SHARD", "256")
