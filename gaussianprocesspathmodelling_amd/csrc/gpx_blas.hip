@@ -481,58 +481,91 @@ __device__ __forceinline__ void potf2_lds(T* __restrict__ Wk, T* __restrict__ Wi
   const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const T zero = (T)0, one = (T)1;
-  // the trailing matrix in registers: wave w owns the lower 16-tiles idx = w, w + 4, w + 8 (< 10; row-major
-  // order idx = tr (tr + 1) / 2 + tc) in accumulator layout
-  v4 R[3];
+  // Round 3, second half — the two phases of a step run on DIFFERENT waves, and phase B of step j beside phase A
+  // of step j + 1:  wave 0 does every phase A (the PW x PW factor, the 64 panel rows: one row per lane; nobody
+  // else ever needed it), waves 1..3 hold the trailing matrix — the ten lower 16-tiles in accumulator layout,
+  //     wave 1: (0,0) (3,0) (3,1)      wave 2: (1,0) (1,1) (2,2) (3,3)      wave 3: (2,0) (2,1) (3,2)
+  // (at most two tiles of any tile column per wave) — and do every phase B.  Per step two barriers:
+  //     wave 0: A(j) -> PB[j & 1], L columns into Wk      | waves 1-3: rest of B(j - PW)
+  //     ---- X(j): the panel is in PB ----
+  //     waves 1-3: update + export of the tile column that holds the NEXT PW columns      | wave 0 idle
+  //     ---- Y(j): the next panel's columns are in Wk ----
+  // so a step costs phase A + the export part (<= 2 tiles) instead of phase A + all of phase B; the panel buffer
+  // is double-buffered (the rest of B(j) reads PB[j & 1] while A(j + PW) writes the other one).
+  const unsigned tcode = wave == 1 ? 0xFF0D0C00u : wave == 2 ? 0x0F0A0504u : wave == 3 ? 0xFF0E0908u : 0xFFFFFFFFu;
+  v4 R[4];
 #pragma unroll
-  for (int sl = 0; sl < 3; ++sl) {
-    const int idx = wave + 4 * sl;
-    const int tr = idx >= 6 ? 3 : idx >= 3 ? 2 : idx >= 1 ? 1 : 0, tc = idx - tr * (tr + 1) / 2;
+  for (int sl = 0; sl < 4; ++sl) {
+    const unsigned code = (tcode >> (8 * sl)) & 0xFFu;
+    const int tr = (int)(code >> 2) & 3, tc = (int)code & 3;
     R[sl] = (v4){0, 0, 0, 0};
-    if (idx < 10) {
+    if (code != 0xFFu) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) R[sl][r] = Wk[(tr * 16 + Num<T>::drow(l4, r)) * PLD + tc * 16 + l15];
     }
   }
+  __syncthreads();  // every tile is in registers before phase A of step 0 starts to overwrite columns of Wk
+  // the rank-PW update of this wave's tile in slot sl with the panel in PBc; `exp`: also write the NEXT panel's
+  // columns [jn, jn + PW) of the tile back to Wk for phase A to read
+  auto update_tile = [&](int sl, const T* PBc, int jn, bool exp) {
+    const unsigned code = (tcode >> (8 * sl)) & 0xFFu;
+    const int tr = (int)(code >> 2) & 3, tc = (int)code & 3;
+    const int colg = tc * 16 + l15;
+    v4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int hh = 0; hh < PW / 4; ++hh) {
+      const T av = PBc[(tr * 16 + l15) * PW + 4 * hh + l4];
+      const T bv = (colg >= jn) ? PBc[colg * PW + 4 * hh + l4] : zero;
+      acc = Num<T>::mfma(av, bv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) R[sl][r] -= acc[r];
+    if (exp && (l15 >> 3) == ((jn >> 3) & 1)) {
+      T* Cp = Wk + (tr * 16) * PLD + colg;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cp[Num<T>::drow(l4, r) * PLD] = R[sl][r];
+    }
+  };
 #ifndef GPX_POTF2_UNROLL
 #pragma unroll 1
 #endif
   for (int j = 0; j < 64; j += PW) {
-    // ---- phase A: PW x PW diagonal factor (redundant per thread, right-looking in
-    //      registers) + this thread's panel row
-    T a[PW][PW], rs[PW];
-    bool okp[PW];
+    T* PBc = PB + ((j / PW) & 1) * (64 * PW);
+    if (wave == 0) {
+      // ---- phase A: PW x PW diagonal factor (right-looking in registers, the same on every lane) + this
+      //      lane's panel row
+      T a[PW][PW], rs[PW];
+      bool okp[PW];
 #pragma unroll
-    for (int c = 0; c < PW; ++c)
+      for (int c = 0; c < PW; ++c)
 #pragma unroll
-      for (int r = c; r < PW; ++r) a[r][c] = Wk[(j + r) * PLD + j + c];
+        for (int r = c; r < PW; ++r) a[r][c] = Wk[(j + r) * PLD + j + c];
 #pragma unroll
-    for (int k = 0; k < PW; ++k) {
-      okp[k] = a[k][k] > zero;
-      rs[k] = Num<T>::rsq(a[k][k]);
+      for (int k = 0; k < PW; ++k) {
+        okp[k] = a[k][k] > zero;
+        rs[k] = Num<T>::rsq(a[k][k]);
 #pragma unroll
-      for (int r = k + 1; r < PW; ++r) a[r][k] *= rs[k];
+        for (int r = k + 1; r < PW; ++r) a[r][k] *= rs[k];
 #pragma unroll
-      for (int c = k + 1; c < PW; ++c)
+        for (int c = k + 1; c < PW; ++c)
 #pragma unroll
-        for (int r = c; r < PW; ++r) a[r][c] -= a[r][k] * a[c][k];
-    }
-    if (tid == 0) {
-      int bad = 0;
+          for (int r = c; r < PW; ++r) a[r][c] -= a[r][k] * a[c][k];
+      }
+      if (lane == 0) {
+        int bad = 0;
 #pragma unroll
-      for (int k = PW - 1; k >= 0; --k)
-        if (!okp[k]) bad = k + 1;  // first non-positive (or NaN) pivot of this step
-      if (bad) atomicMin(info, (int)(gidx0 + j + bad));
+        for (int k = PW - 1; k >= 0; --k)
+          if (!okp[k]) bad = k + 1;  // first non-positive (or NaN) pivot of this step
+        if (bad) atomicMin(info, (int)(gidx0 + j + bad));
 #pragma unroll
-      for (int k = 0; k < PW; ++k) Rinv[j + k] = rs[k];
-    }
-    if (tid < 64) {
-      const int i = tid;
+        for (int k = 0; k < PW; ++k) Rinv[j + k] = rs[k];
+      }
+      const int i = lane;
       T x[PW];
 #pragma unroll
       for (int k = 0; k < PW; ++k) x[k] = zero;
       if (i >= j) {
-        const T* row = Wk + i * PLD + j;
+        T* row = Wk + i * PLD + j;
         const int c = i - j;  // rows of the diagonal block: strictly-upper part is zero
 #pragma unroll
         for (int k = 0; k < PW; ++k) {
@@ -541,47 +574,34 @@ __device__ __forceinline__ void potf2_lds(T* __restrict__ Wk, T* __restrict__ Wi
           for (int m = 0; m < k; ++m) v -= x[m] * a[k][m];
           x[k] = (c < k) ? zero : v * rs[k];
         }
+#pragma unroll
+        for (int k = 0; k < PW; ++k) row[k] = x[k];  // commit the panel: these columns of L are final
       }
 #pragma unroll
-      for (int k = 0; k < PW; ++k) PB[i * PW + k] = x[k];
+      for (int k = 0; k < PW; ++k) PBc[i * PW + k] = x[k];
     }
-    __syncthreads();
+    __syncthreads();  // X(j)
     GPX_STAMP(2 + 2 * (j / PW));
-    // ---- phase B: commit the panel, rank-PW update of the trailing lower tiles — which live in the
-    //      accumulators R[] (round 3), not in LDS: two MFMAs per tile and a register subtraction; only
-    //      the 8 columns the NEXT step factors are written back to Wk for phase A to read.
-    if (tid < 64 && tid >= j) {
-      T* row = Wk + tid * PLD + j;
-#pragma unroll
-      for (int k = 0; k < PW; ++k) row[k] = PB[tid * PW + k];
-    }
     const int jn = j + PW;
     const int t0 = jn >> 4;
+    if (wave != 0) {  // the tile column the next panel lives in: update, export
 #pragma unroll
-    for (int sl = 0; sl < 3; ++sl) {
-      const int idx = wave + 4 * sl;
-      const int tr = idx >= 6 ? 3 : idx >= 3 ? 2 : idx >= 1 ? 1 : 0, tc = idx - tr * (tr + 1) / 2;
-      if (idx < 10 && tc >= t0) {
-        const int colg = tc * 16 + l15;
-        v4 acc = {0, 0, 0, 0};
-#pragma unroll
-        for (int h = 0; h < PW / 4; ++h) {
-          const T av = PB[(tr * 16 + l15) * PW + 4 * h + l4];
-          const T bv = (colg >= jn) ? PB[colg * PW + 4 * h + l4] : zero;
-          acc = Num<T>::mfma(av, bv, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) R[sl][r] -= acc[r];
-        if (tc == t0 && jn < 64 && (l15 >> 3) == ((jn >> 3) & 1)) {  // columns [jn, jn + 8): the next panel
-          T* Cp = Wk + (tr * 16) * PLD + colg;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Cp[Num<T>::drow(l4, r) * PLD] = R[sl][r];
-        }
+      for (int sl = 0; sl < 4; ++sl) {
+        const unsigned code = (tcode >> (8 * sl)) & 0xFFu;
+        if (code != 0xFFu && (int)(code & 3) == t0) update_tile(sl, PBc, jn, jn < 64);
       }
     }
-    __syncthreads();
+    __syncthreads();  // Y(j)
     GPX_STAMP(3 + 2 * (j / PW));
+    if (wave != 0) {  // the tile columns to the right of it: beside phase A of the next step
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        const unsigned code = (tcode >> (8 * sl)) & 0xFFu;
+        if (code != 0xFFu && (int)(code & 3) > t0) update_tile(sl, PBc, jn, false);
+      }
+    }
   }
+  __syncthreads();  // (the last step leaves nothing to update; everybody meets before the inverse)
 
   // ---- inverse, level 0: wave w inverts diagonal block w; lane c < 16 owns column c.  The six
   //      16x16 blocks above the block diagonal are zeroed here (level 2 reads two of them, and the
@@ -665,7 +685,7 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(T* __restrict__ A, int64_
                                                        unsigned flag_val) {
   __shared__ __attribute__((aligned(16))) T Wk[64 * PLD];  // working matrix -> L (lower)
   __shared__ __attribute__((aligned(16))) T Wi[64 * PLD];  // inverse
-  __shared__ __attribute__((aligned(16))) T PB[64 * PW];   // current PW-column panel
+  __shared__ __attribute__((aligned(16))) T PB[2 * 64 * PW];  // the current and the next PW-column panel
   __shared__ __attribute__((aligned(16))) T Tm[32 * TLD];  // product scratch
   __shared__ T Rinv[64];                                    // 1 / L[i][i]
   __builtin_amdgcn_s_setprio(3);
@@ -727,7 +747,7 @@ __global__ __launch_bounds__(256) void potf2_128_kernel(T* __restrict__ A, int64
   using v4 = typename Num<T>::v4;
   __shared__ __attribute__((aligned(16))) T U[64 * PLD];
   __shared__ __attribute__((aligned(16))) T V[64 * PLD];
-  __shared__ __attribute__((aligned(16))) T PB[64 * PW];
+  __shared__ __attribute__((aligned(16))) T PB[2 * 64 * PW];
   __shared__ __attribute__((aligned(16))) T Tm[32 * TLD];
   __shared__ T Rinv[64];
   __builtin_amdgcn_s_setprio(3);

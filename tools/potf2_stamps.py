@@ -40,7 +40,7 @@ print("load + zero            :", s[1] - s[0])
 for j in range(8):
     a = s[2 + 2 * j] - (s[1] if j == 0 else s[1 + 2 * j])
     b = s[3 + 2 * j] - s[2 + 2 * j]
-    print(f"step {j}: phase A {a:6d}   phase B {b:6d}")
+    print(f"step {j}: phase A (wave 0; beside it the rest of the previous step's phase B) {a:6d}   export part of phase B {b:6d}")
 print("inverse (3 levels)     :", s[20] - s[17])
 print("store                  :", s[21] - s[20])
 print("all runs, total:", [int(r[21] - r[0]) for r in rows])
