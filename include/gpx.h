@@ -132,7 +132,7 @@ int gpx_predict(gpx_handle* h, const void* Xs, int64_t M, void* mean, void* var,
  * rows K(Xs, X) ride through the blocked factorisation as bordered rows — the way the right-hand sides already
  * do — and leave it as V^T = (L^-1 K*^T)^T, so the variance solve costs no pass of its own: its M N^2 flops are
  * rows of the trailing updates (at small N they run on the CUs the serial diagonal chain leaves idle; N = 8192,
- * M = 4096: 12.7 -> 11.6 ms per step).  Same results as the two calls up to the rounding of a different
+ * M = 4096: 12.6 -> 11.5 ms per step).  Same results as the two calls up to the rounding of a different
  * summation order; the handle is fitted afterwards exactly as after gpx_fit (gpx_predict, gpx_get_alpha,
  * gpx_lml_grad ... work on it).  *info > 0: not positive definite, nothing was predicted.  Single-device
  * GPX_F64 / GPX_F32 handles and M <= one predict batch (8192 rows); otherwise GPX_E_UNSUPPORTED — call
