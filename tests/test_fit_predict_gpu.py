@@ -84,3 +84,50 @@ def test_fit_predict_reports_a_bad_pivot_and_falls_back_where_unsupported():
         with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0, **kw) as gp:
             mean, var = gp.fit_predict(X, y, Xs)
             assert rel(np.asarray(mean, np.float64), mr, 1e-6) <= 1e-6
+
+
+@pytest.mark.parametrize("env", [{"GPX_SPLIT_STRIP": "0"}, {"GPX_FUSED_STRIP": "1"}, {"GPX_SOLVE_TOP": "0"},
+                                 {"GPX_REST_SPLIT": "0"}, {"GPX_CHAIN_FLAG": "0"}, {"GPX_DIAG_STEP": "64"}])
+def test_fit_predict_under_every_schedule_switch(monkeypatch, env):
+    """The query rows are bordered rows in EVERY schedule of the factorisation (in the round-2 and the fused one they
+    ride in the chain's panel solves and the generic bordered update): same answer, 12 panels of 1024."""
+    X, y, Xs = synthetic_problem(12288, 3, 300, seed=41)
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0) as gp:
+        m0, v0 = gp.fit_predict(X, y, Xs)
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0) as gp:
+        mean, var = gp.fit_predict(X, y, Xs)
+        assert gp.info_ == 0
+        if "GPX_DIAG_STEP" in env:      # another association inside the 128 x 128 diagonal tiles
+            assert rel(mean, m0, 1e-6) <= 1e-9 and rel(var, v0, 1.5e-6) <= 1e-9
+        else:
+            assert np.array_equal(mean, m0) and np.array_equal(var, v0)
+
+
+def test_fit_predict_jitter_escalation_many_query_points_and_buffer_reuse():
+    X, y, Xs = synthetic_problem(2048, 3, 100, seed=9)
+    X[1500] = X[200]                                       # duplicate point, no noise: needs jitter
+    y[1500] = y[200]
+    with GP("rbf", 0.25, 1.0, 0.0, jitter=0.0, max_tries=12) as gp:
+        mean, var = gp.fit_predict(X, y, Xs)
+        assert gp.info_ == 0 and gp.jitter_used_ > 0.0
+        jit = gp.jitter_used_
+        m2, v2 = gp.fit(X, y).predict(Xs)                  # the two calls escalate the same way
+        assert gp.jitter_used_ == jit
+        # cond(K) ~ 1 / jitter ~ 1e11: the oracle is no yardstick here; the two forms of the same library are
+        assert np.max(np.abs(mean - m2)) <= 1e-6 * np.max(np.abs(m2)) and np.max(np.abs(var - v2)) <= 1e-6
+    Xb, yb, Xsb = synthetic_problem(5000, 3, 8200, seed=12)                     # more than one predict batch: two calls
+    Xc, yc, Xsc = synthetic_problem(1500, 3, 90, seed=13)
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0) as gp:
+        mb, vb = gp.fit_predict(Xb, yb, Xsb)
+        m2, v2 = gp.fit(Xb, yb).predict(Xsb)
+        assert np.array_equal(mb, m2) and np.array_equal(vb, v2)
+        big = gp.fit_predict(Xb, yb, Xsb[:4096])                                # grows the buffers ...
+        small = gp.fit_predict(Xc, yc, Xsc)                                     # ... a smaller problem in them
+        refc = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(Xc, yc)
+        mr, vr = refc.predict(Xsc)
+        assert rel(small[0], mr, 1e-6) <= 1e-6 and rel(small[1], vr, 1.5e-6) <= 1e-6
+        m3, v3 = gp.fit(Xc, yc).predict(Xsc)                                    # and a plain fit after it
+        assert rel(m3, mr, 1e-6) <= 1e-6 and rel(v3, vr, 1.5e-6) <= 1e-6
+        assert np.array_equal(big[0], m2[:4096])
