@@ -61,9 +61,11 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(const double* __restrict__
                                                      double sf2, double diag, const double* __restrict__ y,
                                                      const double* __restrict__ alphaT, int64_t lda, int k,
                                                      double sign, double* __restrict__ outT, int64_t ldo) {
-  __shared__ double xb[64 * XMAXD];
-  __shared__ double ab[KMAX * 64];
-  __shared__ double red[3 * 64 * KMAX];
+  // sized by the instantiation (round 3): with KMAX-sized buffers (146 KB) ONE workgroup fitted a CU — one wave per
+  // SIMD walking a latency chain of global load -> barrier -> 16 kernel values -> barrier; 3.5 KB at k = 1, d = 3
+  __shared__ double xb[64 * (D > 0 ? D : XMAXD)];
+  __shared__ double ab[KC * 64];
+  __shared__ double red[3 * 64 * KC];
   const int d = (D > 0) ? D : d_rt;
   const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(const double* __restrict__
   }
   if (g > 0) {
 #pragma unroll
-    for (int c = 0; c < KC; ++c) red[((g - 1) * 64 + lane) * KMAX + c] = acc[c];
+    for (int c = 0; c < KC; ++c) red[((g - 1) * 64 + lane) * KC + c] = acc[c];
   }
   __syncthreads();
   if (g == 0) {
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void kmatvec_kernel(const double* __restrict__
     for (int c = 0; c < KC; ++c)
       if (c < k) {
         double v = acc[c];
-        for (int q = 0; q < 3; ++q) v += red[(q * 64 + lane) * KMAX + c];
+        for (int q = 0; q < 3; ++q) v += red[(q * 64 + lane) * KC + c];
         double out = 0.0;
         if (i < m) out = (y ? y[i * k + c] : 0.0) + sign * (v + diag * alphaT[(int64_t)c * lda + i]);
         outT[(int64_t)c * ldo + i] = out;
