@@ -97,7 +97,7 @@ struct gpx_handle {
   DevBuf AT;
   DevBuf ZT, gpart;  // gpx_lml_grad: L^-T (Npad x ld) and the per-tile partial sums
   // GPX_MIXED: fp64 side of the mixed-precision mode (the fp32 engine uses the buffers above)
-  DevBuf X64, Y64, Xs64, A64, R64, X32, Y32, RT32, Q64, Qs64, Q32, M64, rn;
+  DevBuf X64, Y64, Xs64, A64, R64, X32, Y32, RT32, Q64, Qs64, Q32, M64, rn, Zfew;
   int refine = 0;    // GPX_MIXED: 0 = adaptive, > 0 = fixed iteration count
   DevBuf Tsol;       // predict: compact solved blocks of V^T (2 x batch x (nb + skew))
   DevBuf MTpart;         // split-K partial tiles of the posterior-mean product
@@ -1278,6 +1278,29 @@ void launch_rows_sumsq_y(gpx_handle* h, double* out) {  // ||y||^2: y (N x k) is
   launch_rows_sumsq((const double*)h->Y64.p, 0, 1, h->N * h->k, out, h->st);
 }
 
+// RT (k rows of ld, fp32) <- (L L^T)^-1 RT with the fit's explicit block inverses: a forward and a backward
+// block substitution as streams over the factor (gpx_mixed.hip: rowdot / coldot kernels), one stream, in order.
+int solve_few_f32(gpx_handle* h, float* RT, int k, const float* L, int64_t ld, int64_t n, const float* W, int nb) {
+  int rc;
+  if ((rc = ensure(h, h->Zfew, (size_t)8 * nb * sizeof(float)))) return rc;
+  float* Zs = (float*)h->Zfew.p;
+  hipStream_t st = h->st;
+  for (int64_t o = 0; o < n; o += nb) {  // L z = r
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    const int64_t t0 = o + nbp;
+    launch_few_product(false, true, Zs, nb, W + (o / nb) * (int64_t)nb * nb, nb, nbp, nbp, RT + o, ld, k, st);
+    HIPCHK(h, hipMemcpy2DAsync(RT + o, (size_t)ld * 4, Zs, (size_t)nb * 4, (size_t)nbp * 4, k, hipMemcpyDeviceToDevice, st));
+    launch_few_product(false, false, RT + t0, ld, L + t0 * ld + o, ld, n - t0, nbp, Zs, nb, k, st);
+  }
+  for (int64_t o = ((n - 1) / nb) * nb; o >= 0; o -= nb) {  // L^T x = z
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    launch_few_product(true, true, Zs, nb, W + (o / nb) * (int64_t)nb * nb, nb, nbp, nbp, RT + o, ld, k, st);
+    HIPCHK(h, hipMemcpy2DAsync(RT + o, (size_t)ld * 4, Zs, (size_t)nb * 4, (size_t)nbp * 4, k, hipMemcpyDeviceToDevice, st));
+    launch_few_product(true, false, RT, ld, L + o * ld, ld, o, nbp, Zs, nb, k, st);
+  }
+  return GPX_OK;
+}
+
 int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
               const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter, int32_t mem_kind,
               int64_t* info) {
@@ -1328,6 +1351,11 @@ int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d,
   // A fixed count runs without reading anything back until the end.
   const bool adaptive = h->refine <= 0;
   const int max_it = adaptive ? MIXED_MAX_ITERS : h->refine;
+  // the streaming solver for few right-hand sides needs the fit's explicit block inverses (GPX_FEW_SOLVE=0: slab path)
+  const bool few = [&] {
+    const char* e = getenv("GPX_FEW_SOLVE");
+    return (!e || atoi(e) != 0) && h->nbw > 0 && h->nbw == h->nb && h->nb <= 1024 && h->nb % 128 == 0;
+  }();
   double prev = 0;
   int iters = 0;
   for (int it = 0;; ++it) {
@@ -1351,10 +1379,14 @@ int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d,
     }
     // delta = (L L^T)^-1 r in fp32; alpha += delta in fp64
     launch_rows_f64_to_f32(R64, Npad, (float*)h->RT32.p, ld32, k, RHS_ROWS, N, Npad, st);
-    if ((rc = solve_fwd_enqueue<float>(h, (float*)h->RT32.p, RHS_ROWS, L32, ld32, Npad, h->nb_solve,
-                                       (const float*)h->Winv.p)))
-      return rc;
-    solve_bwd_enqueue<float>(h, (float*)h->RT32.p, RHS_ROWS, L32, ld32, Npad, h->nb_solve, (const float*)h->Winv.p);
+    if (few) {
+      if ((rc = solve_few_f32(h, (float*)h->RT32.p, k, L32, ld32, Npad, (const float*)h->Wblk.p, h->nbw))) return rc;
+    } else {
+      if ((rc = solve_fwd_enqueue<float>(h, (float*)h->RT32.p, RHS_ROWS, L32, ld32, Npad, h->nb_solve,
+                                         (const float*)h->Winv.p)))
+        return rc;
+      solve_bwd_enqueue<float>(h, (float*)h->RT32.p, RHS_ROWS, L32, ld32, Npad, h->nb_solve, (const float*)h->Winv.p);
+    }
     launch_rows_add_f32_to_f64((const float*)h->RT32.p, ld32, A64, Npad, k, N, Npad, 1, st);
   }
   HIPCHK(h, hipMemcpyAsync(hn, rn, 24, hipMemcpyDeviceToHost, st));
@@ -1552,7 +1584,7 @@ void gpx_destroy(gpx_handle* h) {
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->MTpart, &h->var, &h->meanout, &h->G, &h->Pglob,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
                     &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->ZTloc, &h->ZTpack, &h->gpart, &h->Wblk, &h->Ublk, &h->Tsol, &h->X64, &h->Y64, &h->Xs64,
-                    &h->A64, &h->R64, &h->X32, &h->Y32, &h->RT32, &h->Q64, &h->Qs64, &h->Q32, &h->M64, &h->rn})
+                    &h->A64, &h->R64, &h->X32, &h->Y32, &h->RT32, &h->Q64, &h->Qs64, &h->Q32, &h->M64, &h->rn, &h->Zfew})
     release(*b);
   destroy_comm(h);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);

@@ -154,6 +154,121 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
   if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- triangular solves with FEW right-hand sides (the refinement's delta = (L L^T)^-1 r) -----------------------
+// With k <= 8 right-hand sides a block substitution is a STREAM over the factor: block solve = a product with the
+// explicit block inverse W_p, update = a matrix-vector product with the panel (forward: rows below, one wave per
+// row) or with the row block (backward: columns to the left, one lane per column pair, sixteen waves over the
+// block's rows) — bandwidth-bound launches of the whole GPU instead of slab solves and 64-row MFMA updates that are
+// 20-30 us of launch and latency each.  Fixed summation order everywhere (no atomics).
+constexpr int FEW_NJ = 1024;  // widest block (the panel width's maximum is 2048: wider falls back to the slab path)
+
+// out[c * ldo + i] (ASSIGN: = ; else -=) sum_{j < nj} M[i * ldm + j] * v[c * ldv + j],  i < ni, c < k <= KC
+template <int KC, bool ASSIGN>
+__global__ __launch_bounds__(256) void rowdot_kernel(float* __restrict__ out, int64_t ldo, const float* __restrict__ M,
+                                                     int64_t ldm, int64_t ni, int nj, const float* __restrict__ v,
+                                                     int64_t ldv, int k) {
+  __shared__ __attribute__((aligned(16))) float vs[KC * FEW_NJ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < KC * nj; e += 256) {
+    const int c = e / nj, j = e - c * nj;
+    vs[c * FEW_NJ + j] = c < k ? v[(int64_t)c * ldv + j] : 0.f;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= ni) return;
+  float acc[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) acc[c] = 0.f;
+  const float* row = M + i * ldm;
+  for (int j = lane * 4; j < nj; j += 256) {
+    const float4 m = *reinterpret_cast<const float4*>(row + j);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const float4 x = *reinterpret_cast<const float4*>(&vs[c * FEW_NJ + j]);
+      acc[c] += (m.x * x.x + m.y * x.y) + (m.z * x.z + m.w * x.w);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+      if (c < k) {
+        float* p = out + (int64_t)c * ldo + i;
+        *p = ASSIGN ? acc[c] : *p - acc[c];
+      }
+  }
+}
+
+// out[c * ldo + i] (ASSIGN: = ; else -=) sum_{j < nj} M[j * ldm + i] * v[c * ldv + j],  i < ni (a multiple of 128);
+// workgroup = 128 columns (lane = 2 of them) x 16 waves, wave w takes the rows j = w, w + 16, ...
+template <int KC, bool ASSIGN>
+__global__ __launch_bounds__(1024) void coldot_kernel(float* __restrict__ out, int64_t ldo, const float* __restrict__ M,
+                                                      int64_t ldm, int64_t ni, int nj, const float* __restrict__ v,
+                                                      int64_t ldv, int k) {
+  __shared__ __attribute__((aligned(16))) float vs[KC * FEW_NJ];
+  __shared__ float red[16 * KC * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < KC * nj; e += 1024) {
+    const int c = e / nj, j = e - c * nj;
+    vs[c * FEW_NJ + j] = c < k ? v[(int64_t)c * ldv + j] : 0.f;
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 128 + lane * 2;
+  float a0[KC], a1[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) a0[c] = a1[c] = 0.f;
+  const float* col = M + i;
+#pragma unroll 8
+  for (int j = wave; j < nj; j += 16) {
+    const float2 m = *reinterpret_cast<const float2*>(col + (int64_t)j * ldm);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const float x = vs[c * FEW_NJ + j];
+      a0[c] += m.x * x;
+      a1[c] += m.y * x;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    red[(wave * KC + c) * 128 + lane * 2] = a0[c];
+    red[(wave * KC + c) * 128 + lane * 2 + 1] = a1[c];
+  }
+  __syncthreads();
+  for (int e = tid; e < KC * 128; e += 1024) {
+    const int c = e >> 7, col128 = e & 127;
+    if (c < k) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) sacc += red[(w * KC + c) * 128 + col128];
+      float* p = out + (int64_t)c * ldo + (int64_t)blockIdx.x * 128 + col128;
+      *p = ASSIGN ? sacc : *p - sacc;
+    }
+  }
+}
+
+template <int KC>
+void launch_few_kc(bool cols, bool assign, float* out, int64_t ldo, const float* M, int64_t ldm, int64_t ni, int nj,
+                   const float* v, int64_t ldv, int k, hipStream_t st) {
+  if (ni <= 0) return;
+  if (!cols) {
+    dim3 grid((unsigned)((ni + 3) / 4)), block(256);
+    if (assign)
+      hipLaunchKernelGGL((rowdot_kernel<KC, true>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
+    else
+      hipLaunchKernelGGL((rowdot_kernel<KC, false>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
+  } else {
+    dim3 grid((unsigned)(ni / 128)), block(1024);
+    if (assign)
+      hipLaunchKernelGGL((coldot_kernel<KC, true>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
+    else
+      hipLaunchKernelGGL((coldot_kernel<KC, false>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
+  }
+}
+
 template <int KERNEL, int KC>
 void launch_kmatvec_kc(const double* As, int64_t m, int64_t mpad, const double* Bs, int64_t npad, int d, double sf2,
                        double diag, const double* y, const double* alphaT, int64_t lda, int k, double sign,
@@ -186,6 +301,17 @@ void launch_kmatvec(int kernel, const double* As, int64_t m, int64_t mpad, const
     launch_kmatvec_k<0>(As, m, mpad, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo, st);
   else
     launch_kmatvec_k<1>(As, m, mpad, Bs, npad, d, sf2, diag, y, alphaT, lda, k, sign, outT, ldo, st);
+}
+
+// rows (cols = false): out[c][i] (=|-=) sum_j M[i][j] v[c][j];  columns (cols = true): ... sum_j M[j][i] v[c][j]
+void launch_few_product(bool cols, bool assign, float* out, int64_t ldo, const float* M, int64_t ldm, int64_t ni,
+                        int nj, const float* v, int64_t ldv, int k, hipStream_t st) {
+  if (k == 1)
+    launch_few_kc<1>(cols, assign, out, ldo, M, ldm, ni, nj, v, ldv, k, st);
+  else if (k == 2)
+    launch_few_kc<2>(cols, assign, out, ldo, M, ldm, ni, nj, v, ldv, k, st);
+  else
+    launch_few_kc<KMAX>(cols, assign, out, ldo, M, ldm, ni, nj, v, ldv, k, st);
 }
 
 void launch_f64_to_f32(const double* in, float* out, int64_t count, hipStream_t st) {
