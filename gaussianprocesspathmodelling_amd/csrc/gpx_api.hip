@@ -1280,12 +1280,13 @@ void launch_rows_sumsq_y(gpx_handle* h, double* out) {  // ||y||^2: y (N x k) is
 
 // RT (k rows of ld, fp32) <- (L L^T)^-1 RT with the fit's explicit block inverses: a forward and a backward
 // block substitution as streams over the factor (gpx_mixed.hip: rowdot / coldot kernels), one stream, in order.
-int solve_few_f32(gpx_handle* h, float* RT, int k, const float* L, int64_t ld, int64_t n, const float* W, int nb) {
+int solve_few_f32(gpx_handle* h, float* RT, int k, const float* L, int64_t ld, int64_t n, const float* W, int nb,
+                  bool forward = true) {
   int rc;
   if ((rc = ensure(h, h->Zfew, (size_t)8 * nb * sizeof(float)))) return rc;
   float* Zs = (float*)h->Zfew.p;
   hipStream_t st = h->st;
-  for (int64_t o = 0; o < n; o += nb) {  // L z = r
+  for (int64_t o = 0; forward && o < n; o += nb) {  // L z = r
     const int nbp = (int)std::min<int64_t>(nb, n - o);
     const int64_t t0 = o + nbp;
     launch_few_product(false, true, Zs, nb, W + (o / nb) * (int64_t)nb * nb, nb, nbp, nbp, RT + o, ld, k, st);
@@ -1330,7 +1331,23 @@ int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d,
   if (*info != 0) return GPX_OK;
   const int64_t ld32 = h->ld;
   if ((rc = ensure(h, h->RT32, (size_t)RHS_ROWS * ld32 * 4))) return rc;
-  if ((rc = ensure_alpha<float>(h))) return rc;
+  // the streaming solver for few right-hand sides needs the fit's explicit block inverses (GPX_FEW_SOLVE=0: slab path)
+  const bool few = [&] {
+    const char* e = getenv("GPX_FEW_SOLVE");
+    return (!e || atoi(e) != 0) && h->nbw > 0 && h->nbw == h->nb && h->nb <= 1024 && h->nb % 128 == 0;
+  }();
+  if (few) {  // alpha32 = L^-T z: the backward half of the same stream (ensure_alpha with the few-rhs solver)
+    if ((rc = ensure(h, h->AT, (size_t)RHS_ROWS * ld32 * 4))) return rc;
+    PhaseScope ps(h, &h->tm.solve);
+    HIPCHK(h, hipMemcpyAsync(h->AT.p, h->zT, (size_t)RHS_ROWS * ld32 * 4, hipMemcpyDeviceToDevice, h->st));
+    if ((rc = solve_few_f32(h, (float*)h->AT.p, k, (const float*)h->Lfac, ld32, Npad, (const float*)h->Wblk.p, h->nbw,
+                            false)))
+      return rc;
+    h->alphaT = h->AT.p;
+    h->alpha_ready = true;
+  } else if ((rc = ensure_alpha<float>(h))) {
+    return rc;
+  }
   double* A64 = (double*)h->A64.p;
   double* R64 = (double*)h->R64.p;
   double* rn = (double*)h->rn.p;
@@ -1351,11 +1368,6 @@ int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d,
   // A fixed count runs without reading anything back until the end.
   const bool adaptive = h->refine <= 0;
   const int max_it = adaptive ? MIXED_MAX_ITERS : h->refine;
-  // the streaming solver for few right-hand sides needs the fit's explicit block inverses (GPX_FEW_SOLVE=0: slab path)
-  const bool few = [&] {
-    const char* e = getenv("GPX_FEW_SOLVE");
-    return (!e || atoi(e) != 0) && h->nbw > 0 && h->nbw == h->nb && h->nb <= 1024 && h->nb % 128 == 0;
-  }();
   double prev = 0;
   int iters = 0;
   for (int it = 0;; ++it) {
