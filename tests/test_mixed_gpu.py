@@ -19,10 +19,12 @@ pytestmark = pytest.mark.gpu
     (2500, 130, 1, "matern52", (0.3, 0.2, 0.25), 1e-2),
     (4000, 300, 2, "rbf", (0.3, 0.2, 0.25), 1e-2),
     (1000, 77, 1, "rbf", 0.25, 1e-2),
+    (2700, 90, 5, "rbf", 0.25, 1e-2),          # 3 .. 8 targets: the KC = 8 instantiation of the refinement kernels; three
+    (3300, 64, 8, "matern52", 0.3, 1e-2),      # panels, the last one 640 / 256 wide (streaming few-right-hand-side solves)
 ])
 def test_refined_mean_meets_the_fp64_bar(N, M, k, kernel, ls, noise):
     X, y, Xs = synthetic_problem(N, 3, M, seed=N)
-    Y = y if k == 1 else np.stack([y, np.cos(2 * y)], axis=1)
+    Y = y if k == 1 else np.stack([np.cos((c + 1) * y) if c else y for c in range(k)], axis=1)
     ref = OracleGP(kernel, ls, 1.5, noise, jitter=0.0).fit(X, Y)
     mr, vr = ref.predict(Xs)
     with GP(kernel, ls, 1.5, noise, jitter=0.0, dtype="mixed", refine=3) as gp:
