@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GPX_ABI_VERSION 4
+#define GPX_ABI_VERSION 4 /* v4: + gpx_fit_predict (v3: gpx_set_flags, refine semantics, one-rank groups) */
 
 /* kernel family — SURVEY.md §8 row a1 (nearest reference code: the pairwise
  * distance loop trajectories.calc_distance, GPmap.py:114-121, and the unused
