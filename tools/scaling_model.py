@@ -18,7 +18,7 @@ import json
 RATE = {1024: 68.3e12, 512: 63.2e12, 256: 55e12}   # sharded trailing-update kernel, flop/s (one-rank schedule
                                                     # 68.3 TF at nb=1024, 63.2 at nb=512; 256: assumption)
 RATE_1GPU = 69.0e12                                 # unsharded SYRK under the bench (profiles/r03_start_bench.json: 69.6)
-CHAIN_US_PER_128 = 75.0                             # diagonal chain alone, per 128 columns (profiles/r03_c2_chain_gaps.txt)
+CHAIN_US_PER_128 = 60.0                             # diagonal chain alone, per 128 columns (profiles/r03_c2_chain_gaps.txt: 57.5-60 after the POTF2 phase overlap)
 CHAIN_STRETCH = 5.6                                 # the same chain beside a busy trailing update: 214 ms / 64 blocks
                                                     # (r03 bench chol_diag) against 0.6 ms per block alone
 SOLVE_RATE = 45e12                                  # panel solve as a dense product with W_p (ltri kernel; DESIGN §5.0: 39 -> ~45 TF)
