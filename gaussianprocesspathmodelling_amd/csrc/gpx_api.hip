@@ -18,9 +18,12 @@
 //   P       2 x [Npad+64][nb+skew]  compact copies of the current / next panel (SYRK operand)
 //   VT      [MB][ld]            K* and, after the forward solve, V^T — one batch of MB <= 8192 query points
 //   ZT      [Npad][ld]          L^-T, on demand, for gpx_lml_grad
-// Streams: st (main), st2 (look-ahead: diagonal block + panel solve of the next panel, high
-// priority), st3 (side: block-inverse extension), st4 (copies of solved panels / blocks back
-// into their matrices).
+//                               (gpx_fit_predict: Mpad more rows below the right-hand sides carry K* -> V^T)
+// Streams: st (main: the throughput work — rows below the next diagonal block, REST, the rows of the panel
+// solve nobody on the chain needs, bordered / query rows), st2 (look-ahead CHAIN, high priority: update of the
+// next diagonal block, its factorisation, the panel solve of the rows of the diagonal block after it), st3
+// (side: block-inverse extension, parked on the POTF2's device flag), st4 (copies of solved panels / blocks
+// back into their matrices).  Schedule: chol_enqueue.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
