@@ -992,6 +992,40 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   return GPX_OK;
 }
 
+// RT (k <= 8 rows of ld) <- (L L^T)^-1 RT (or only L^-T RT) with the fit's explicit block inverses: a forward and a
+// backward block substitution as streams over the factor (gpx_mixed.hip: rowdot / coldot kernels), one stream, in order.
+template <typename T>
+int solve_few(gpx_handle* h, T* RT, int k, const T* L, int64_t ld, int64_t n, const T* W, int nb, bool forward = true) {
+  int rc;
+  if ((rc = ensure(h, h->Zfew, (size_t)8 * nb * sizeof(T)))) return rc;
+  T* Zs = (T*)h->Zfew.p;
+  hipStream_t st = h->st;
+  for (int64_t o = 0; forward && o < n; o += nb) {  // L z = r
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    const int64_t t0 = o + nbp;
+    launch_few_product<T>(false, true, Zs, nb, W + (o / nb) * (int64_t)nb * nb, nb, nbp, nbp, RT + o, ld, k, st);
+    HIPCHK(h, hipMemcpy2DAsync(RT + o, (size_t)ld * sizeof(T), Zs, (size_t)nb * sizeof(T), (size_t)nbp * sizeof(T), k,
+                               hipMemcpyDeviceToDevice, st));
+    launch_few_product<T>(false, false, RT + t0, ld, L + t0 * ld + o, ld, n - t0, nbp, Zs, nb, k, st);
+  }
+  for (int64_t o = ((n - 1) / nb) * nb; o >= 0; o -= nb) {  // L^T x = z
+    const int nbp = (int)std::min<int64_t>(nb, n - o);
+    launch_few_product<T>(true, true, Zs, nb, W + (o / nb) * (int64_t)nb * nb, nb, nbp, nbp, RT + o, ld, k, st);
+    HIPCHK(h, hipMemcpy2DAsync(RT + o, (size_t)ld * sizeof(T), Zs, (size_t)nb * sizeof(T), (size_t)nbp * sizeof(T), k,
+                               hipMemcpyDeviceToDevice, st));
+    launch_few_product<T>(true, false, RT, ld, L + o * ld, ld, o, nbp, Zs, nb, k, st);
+  }
+  return GPX_OK;
+}
+
+// the streaming solver needs the fit's explicit block inverses, at most 8 right-hand sides and blocks <= 1024 wide
+// (GPX_FEW_SOLVE=0: always the slab path)
+bool few_solver_applies(const gpx_handle* h) {
+  const char* e = getenv("GPX_FEW_SOLVE");
+  return (!e || atoi(e) != 0) && h->nbw > 0 && h->nbw == h->nb && h->nb <= 1024 && h->nb % 128 == 0 && h->k <= 8 &&
+         !h->comm && h->Wblk.p;
+}
+
 // alpha^T = z^T L^-1 on a copy of the bordered rows (z stays available for V^T z)
 template <typename T>
 int ensure_alpha(gpx_handle* h) {
@@ -1001,8 +1035,12 @@ int ensure_alpha(gpx_handle* h) {
   PhaseScope ps(h, &h->tm.solve);
   HIPCHK(h, hipMemcpyAsync(h->AT.p, h->zT, (size_t)RHS_ROWS * h->ld * sizeof(T), hipMemcpyDeviceToDevice,
                            h->st));
-  solve_bwd_enqueue<T>(h, (T*)h->AT.p, RHS_ROWS, (const T*)h->Lfac, h->ld, h->Npad, h->nb_solve,
-                       (const T*)h->Winv.p);
+  if (few_solver_applies(h)) {  // k <= 8 targets: the back substitution as a stream over the factor (round 3)
+    if ((rc = solve_few<T>(h, (T*)h->AT.p, h->k, (const T*)h->Lfac, h->ld, h->Npad, (const T*)h->Wblk.p, h->nbw, false)))
+      return rc;
+  } else
+    solve_bwd_enqueue<T>(h, (T*)h->AT.p, RHS_ROWS, (const T*)h->Lfac, h->ld, h->Npad, h->nb_solve,
+                         (const T*)h->Winv.p);
   h->alphaT = h->AT.p;
   h->alpha_ready = true;
   return GPX_OK;
@@ -1281,30 +1319,6 @@ void launch_rows_sumsq_y(gpx_handle* h, double* out) {  // ||y||^2: y (N x k) is
   launch_rows_sumsq((const double*)h->Y64.p, 0, 1, h->N * h->k, out, h->st);
 }
 
-// RT (k rows of ld, fp32) <- (L L^T)^-1 RT with the fit's explicit block inverses: a forward and a backward
-// block substitution as streams over the factor (gpx_mixed.hip: rowdot / coldot kernels), one stream, in order.
-int solve_few_f32(gpx_handle* h, float* RT, int k, const float* L, int64_t ld, int64_t n, const float* W, int nb,
-                  bool forward = true) {
-  int rc;
-  if ((rc = ensure(h, h->Zfew, (size_t)8 * nb * sizeof(float)))) return rc;
-  float* Zs = (float*)h->Zfew.p;
-  hipStream_t st = h->st;
-  for (int64_t o = 0; forward && o < n; o += nb) {  // L z = r
-    const int nbp = (int)std::min<int64_t>(nb, n - o);
-    const int64_t t0 = o + nbp;
-    launch_few_product(false, true, Zs, nb, W + (o / nb) * (int64_t)nb * nb, nb, nbp, nbp, RT + o, ld, k, st);
-    HIPCHK(h, hipMemcpy2DAsync(RT + o, (size_t)ld * 4, Zs, (size_t)nb * 4, (size_t)nbp * 4, k, hipMemcpyDeviceToDevice, st));
-    launch_few_product(false, false, RT + t0, ld, L + t0 * ld + o, ld, n - t0, nbp, Zs, nb, k, st);
-  }
-  for (int64_t o = ((n - 1) / nb) * nb; o >= 0; o -= nb) {  // L^T x = z
-    const int nbp = (int)std::min<int64_t>(nb, n - o);
-    launch_few_product(true, true, Zs, nb, W + (o / nb) * (int64_t)nb * nb, nb, nbp, nbp, RT + o, ld, k, st);
-    HIPCHK(h, hipMemcpy2DAsync(RT + o, (size_t)ld * 4, Zs, (size_t)nb * 4, (size_t)nbp * 4, k, hipMemcpyDeviceToDevice, st));
-    launch_few_product(true, false, RT, ld, L + o * ld, ld, o, nbp, Zs, nb, k, st);
-  }
-  return GPX_OK;
-}
-
 int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
               const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter, int32_t mem_kind,
               int64_t* info) {
@@ -1334,23 +1348,8 @@ int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d,
   if (*info != 0) return GPX_OK;
   const int64_t ld32 = h->ld;
   if ((rc = ensure(h, h->RT32, (size_t)RHS_ROWS * ld32 * 4))) return rc;
-  // the streaming solver for few right-hand sides needs the fit's explicit block inverses (GPX_FEW_SOLVE=0: slab path)
-  const bool few = [&] {
-    const char* e = getenv("GPX_FEW_SOLVE");
-    return (!e || atoi(e) != 0) && h->nbw > 0 && h->nbw == h->nb && h->nb <= 1024 && h->nb % 128 == 0;
-  }();
-  if (few) {  // alpha32 = L^-T z: the backward half of the same stream (ensure_alpha with the few-rhs solver)
-    if ((rc = ensure(h, h->AT, (size_t)RHS_ROWS * ld32 * 4))) return rc;
-    PhaseScope ps(h, &h->tm.solve);
-    HIPCHK(h, hipMemcpyAsync(h->AT.p, h->zT, (size_t)RHS_ROWS * ld32 * 4, hipMemcpyDeviceToDevice, h->st));
-    if ((rc = solve_few_f32(h, (float*)h->AT.p, k, (const float*)h->Lfac, ld32, Npad, (const float*)h->Wblk.p, h->nbw,
-                            false)))
-      return rc;
-    h->alphaT = h->AT.p;
-    h->alpha_ready = true;
-  } else if ((rc = ensure_alpha<float>(h))) {
-    return rc;
-  }
+  const bool few = few_solver_applies(h);
+  if ((rc = ensure_alpha<float>(h))) return rc;
   double* A64 = (double*)h->A64.p;
   double* R64 = (double*)h->R64.p;
   double* rn = (double*)h->rn.p;
@@ -1395,7 +1394,7 @@ int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d,
     // delta = (L L^T)^-1 r in fp32; alpha += delta in fp64
     launch_rows_f64_to_f32(R64, Npad, (float*)h->RT32.p, ld32, k, RHS_ROWS, N, Npad, st);
     if (few) {
-      if ((rc = solve_few_f32(h, (float*)h->RT32.p, k, L32, ld32, Npad, (const float*)h->Wblk.p, h->nbw))) return rc;
+      if ((rc = solve_few<float>(h, (float*)h->RT32.p, k, L32, ld32, Npad, (const float*)h->Wblk.p, h->nbw))) return rc;
     } else {
       if ((rc = solve_fwd_enqueue<float>(h, (float*)h->RT32.p, RHS_ROWS, L32, ld32, Npad, h->nb_solve,
                                          (const float*)h->Winv.p)))

@@ -192,9 +192,10 @@ void launch_rows_f64_to_f32(const double* src, int64_t lds, float* dst, int64_t 
 void launch_rows_add_f32_to_f64(const float* src, int64_t lds, double* dst, int64_t ldd, int rows, int64_t n,
                                 int64_t npad, int acc, hipStream_t st);
 void launch_rows_sumsq(const double* src, int64_t lds, int rows, int64_t n, double* out, hipStream_t st);
-// few right-hand sides (k <= 8), fp32: out[c][i] (= | -=) sum_j M[i][j] v[c][j]  (cols: M[j][i]); nj <= 1024, cols: ni % 128 == 0
-void launch_few_product(bool cols, bool assign, float* out, int64_t ldo, const float* M, int64_t ldm, int64_t ni,
-                        int nj, const float* v, int64_t ldv, int k, hipStream_t st);
+// few right-hand sides (k <= 8): out[c][i] (= | -=) sum_j M[i][j] v[c][j]  (cols: M[j][i]); nj <= 1024, cols: ni % 128 == 0
+template <typename T>
+void launch_few_product(bool cols, bool assign, T* out, int64_t ldo, const T* M, int64_t ldm, int64_t ni, int nj,
+                        const T* v, int64_t ldv, int k, hipStream_t st);
 
 // ---- path distance (gpx_paths.hip) -----------------------------------------------------------
 // D (P, ldd)[p][c] = sum_i ||paths[p][i] - cents[c][i]||, paths (P, L, 2), cents (C <= 64, L <= 64, 2)

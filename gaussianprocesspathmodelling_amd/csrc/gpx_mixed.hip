@@ -162,31 +162,54 @@ __global__ __launch_bounds__(256) void rows_sumsq_kernel(const double* __restric
 // 20-30 us of launch and latency each.  Fixed summation order everywhere (no atomics).
 constexpr int FEW_NJ = 1024;  // widest block (the panel width's maximum is 2048: wider falls back to the slab path)
 
+// 16-byte row loads (4 floats / 2 doubles per lane), 8-byte column loads (2 floats / 1 double per lane)
+template <typename T>
+struct FewVec;
+template <>
+struct FewVec<float> {
+  static constexpr int NR = 4, NC = 2;
+  static __device__ __forceinline__ float dot(const float* a, const float* b) {
+    const float4 m = *reinterpret_cast<const float4*>(a), x = *reinterpret_cast<const float4*>(b);
+    return (m.x * x.x + m.y * x.y) + (m.z * x.z + m.w * x.w);
+  }
+  static __device__ __forceinline__ void ldc(const float* p, float (&v)[2]) {
+    const float2 m = *reinterpret_cast<const float2*>(p);
+    v[0] = m.x;
+    v[1] = m.y;
+  }
+};
+template <>
+struct FewVec<double> {
+  static constexpr int NR = 2, NC = 1;
+  static __device__ __forceinline__ double dot(const double* a, const double* b) {
+    const double2 m = *reinterpret_cast<const double2*>(a), x = *reinterpret_cast<const double2*>(b);
+    return m.x * x.x + m.y * x.y;
+  }
+  static __device__ __forceinline__ void ldc(const double* p, double (&v)[1]) { v[0] = *p; }
+};
+
 // out[c * ldo + i] (ASSIGN: = ; else -=) sum_{j < nj} M[i * ldm + j] * v[c * ldv + j],  i < ni, c < k <= KC
-template <int KC, bool ASSIGN>
-__global__ __launch_bounds__(256) void rowdot_kernel(float* __restrict__ out, int64_t ldo, const float* __restrict__ M,
-                                                     int64_t ldm, int64_t ni, int nj, const float* __restrict__ v,
+template <typename T, int KC, bool ASSIGN>
+__global__ __launch_bounds__(256) void rowdot_kernel(T* __restrict__ out, int64_t ldo, const T* __restrict__ M,
+                                                     int64_t ldm, int64_t ni, int nj, const T* __restrict__ v,
                                                      int64_t ldv, int k) {
-  __shared__ __attribute__((aligned(16))) float vs[KC * FEW_NJ];
+  constexpr int NR = FewVec<T>::NR;
+  __shared__ __attribute__((aligned(16))) T vs[KC * FEW_NJ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < KC * nj; e += 256) {
     const int c = e / nj, j = e - c * nj;
-    vs[c * FEW_NJ + j] = c < k ? v[(int64_t)c * ldv + j] : 0.f;
+    vs[c * FEW_NJ + j] = c < k ? v[(int64_t)c * ldv + j] : (T)0;
   }
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= ni) return;
-  float acc[KC];
+  T acc[KC];
 #pragma unroll
-  for (int c = 0; c < KC; ++c) acc[c] = 0.f;
-  const float* row = M + i * ldm;
-  for (int j = lane * 4; j < nj; j += 256) {
-    const float4 m = *reinterpret_cast<const float4*>(row + j);
+  for (int c = 0; c < KC; ++c) acc[c] = (T)0;
+  const T* row = M + i * ldm;
+  for (int j = lane * NR; j < nj; j += 64 * NR) {
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      const float4 x = *reinterpret_cast<const float4*>(&vs[c * FEW_NJ + j]);
-      acc[c] += (m.x * x.x + m.y * x.y) + (m.z * x.z + m.w * x.w);
-    }
+    for (int c = 0; c < KC; ++c) acc[c] += FewVec<T>::dot(row + j, &vs[c * FEW_NJ + j]);
   }
 #pragma unroll
   for (int c = 0; c < KC; ++c) {
@@ -197,75 +220,78 @@ __global__ __launch_bounds__(256) void rowdot_kernel(float* __restrict__ out, in
 #pragma unroll
     for (int c = 0; c < KC; ++c)
       if (c < k) {
-        float* p = out + (int64_t)c * ldo + i;
+        T* p = out + (int64_t)c * ldo + i;
         *p = ASSIGN ? acc[c] : *p - acc[c];
       }
   }
 }
 
-// out[c * ldo + i] (ASSIGN: = ; else -=) sum_{j < nj} M[j * ldm + i] * v[c * ldv + j],  i < ni (a multiple of 128);
-// workgroup = 128 columns (lane = 2 of them) x 16 waves, wave w takes the rows j = w, w + 16, ...
-template <int KC, bool ASSIGN>
-__global__ __launch_bounds__(1024) void coldot_kernel(float* __restrict__ out, int64_t ldo, const float* __restrict__ M,
-                                                      int64_t ldm, int64_t ni, int nj, const float* __restrict__ v,
+// out[c * ldo + i] (ASSIGN: = ; else -=) sum_{j < nj} M[j * ldm + i] * v[c * ldv + j],  i < ni (a multiple of 64 NC);
+// workgroup = 64 NC columns (lane = NC of them) x 16 waves, wave w takes the rows j = w, w + 16, ...
+template <typename T, int KC, bool ASSIGN>
+__global__ __launch_bounds__(1024) void coldot_kernel(T* __restrict__ out, int64_t ldo, const T* __restrict__ M,
+                                                      int64_t ldm, int64_t ni, int nj, const T* __restrict__ v,
                                                       int64_t ldv, int k) {
-  __shared__ __attribute__((aligned(16))) float vs[KC * FEW_NJ];
-  __shared__ float red[16 * KC * 128];
+  constexpr int NC = FewVec<T>::NC, WC = 64 * NC;
+  __shared__ __attribute__((aligned(16))) T vs[KC * FEW_NJ];
+  __shared__ T red[16 * KC * WC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < KC * nj; e += 1024) {
     const int c = e / nj, j = e - c * nj;
-    vs[c * FEW_NJ + j] = c < k ? v[(int64_t)c * ldv + j] : 0.f;
+    vs[c * FEW_NJ + j] = c < k ? v[(int64_t)c * ldv + j] : (T)0;
   }
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * 128 + lane * 2;
-  float a0[KC], a1[KC];
+  const int64_t i = (int64_t)blockIdx.x * WC + lane * NC;
+  T a[KC][NC];
 #pragma unroll
-  for (int c = 0; c < KC; ++c) a0[c] = a1[c] = 0.f;
-  const float* col = M + i;
+  for (int c = 0; c < KC; ++c)
+#pragma unroll
+    for (int q = 0; q < NC; ++q) a[c][q] = (T)0;
+  const T* col = M + i;
 #pragma unroll 8
   for (int j = wave; j < nj; j += 16) {
-    const float2 m = *reinterpret_cast<const float2*>(col + (int64_t)j * ldm);
+    T m[NC];
+    FewVec<T>::ldc(col + (int64_t)j * ldm, m);
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
-      const float x = vs[c * FEW_NJ + j];
-      a0[c] += m.x * x;
-      a1[c] += m.y * x;
+      const T x = vs[c * FEW_NJ + j];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) a[c][q] += m[q] * x;
     }
   }
 #pragma unroll
-  for (int c = 0; c < KC; ++c) {
-    red[(wave * KC + c) * 128 + lane * 2] = a0[c];
-    red[(wave * KC + c) * 128 + lane * 2 + 1] = a1[c];
-  }
-  __syncthreads();
-  for (int e = tid; e < KC * 128; e += 1024) {
-    const int c = e >> 7, col128 = e & 127;
-    if (c < k) {
-      float sacc = 0.f;
+  for (int c = 0; c < KC; ++c)
 #pragma unroll
-      for (int w = 0; w < 16; ++w) sacc += red[(w * KC + c) * 128 + col128];
-      float* p = out + (int64_t)c * ldo + (int64_t)blockIdx.x * 128 + col128;
+    for (int q = 0; q < NC; ++q) red[(wave * KC + c) * WC + lane * NC + q] = a[c][q];
+  __syncthreads();
+  for (int e = tid; e < KC * WC; e += 1024) {
+    const int c = e / WC, cc = e - c * WC;
+    if (c < k) {
+      T sacc = (T)0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) sacc += red[(w * KC + c) * WC + cc];
+      T* p = out + (int64_t)c * ldo + (int64_t)blockIdx.x * WC + cc;
       *p = ASSIGN ? sacc : *p - sacc;
     }
   }
 }
 
-template <int KC>
-void launch_few_kc(bool cols, bool assign, float* out, int64_t ldo, const float* M, int64_t ldm, int64_t ni, int nj,
-                   const float* v, int64_t ldv, int k, hipStream_t st) {
+template <typename T, int KC>
+void launch_few_kc(bool cols, bool assign, T* out, int64_t ldo, const T* M, int64_t ldm, int64_t ni, int nj,
+                   const T* v, int64_t ldv, int k, hipStream_t st) {
   if (ni <= 0) return;
   if (!cols) {
     dim3 grid((unsigned)((ni + 3) / 4)), block(256);
     if (assign)
-      hipLaunchKernelGGL((rowdot_kernel<KC, true>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
+      hipLaunchKernelGGL((rowdot_kernel<T, KC, true>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
     else
-      hipLaunchKernelGGL((rowdot_kernel<KC, false>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
+      hipLaunchKernelGGL((rowdot_kernel<T, KC, false>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
   } else {
-    dim3 grid((unsigned)(ni / 128)), block(1024);
+    dim3 grid((unsigned)(ni / (64 * FewVec<T>::NC))), block(1024);
     if (assign)
-      hipLaunchKernelGGL((coldot_kernel<KC, true>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
+      hipLaunchKernelGGL((coldot_kernel<T, KC, true>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
     else
-      hipLaunchKernelGGL((coldot_kernel<KC, false>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
+      hipLaunchKernelGGL((coldot_kernel<T, KC, false>), grid, block, 0, st, out, ldo, M, ldm, ni, nj, v, ldv, k);
   }
 }
 
@@ -304,15 +330,20 @@ void launch_kmatvec(int kernel, const double* As, int64_t m, int64_t mpad, const
 }
 
 // rows (cols = false): out[c][i] (=|-=) sum_j M[i][j] v[c][j];  columns (cols = true): ... sum_j M[j][i] v[c][j]
-void launch_few_product(bool cols, bool assign, float* out, int64_t ldo, const float* M, int64_t ldm, int64_t ni,
-                        int nj, const float* v, int64_t ldv, int k, hipStream_t st) {
+template <typename T>
+void launch_few_product(bool cols, bool assign, T* out, int64_t ldo, const T* M, int64_t ldm, int64_t ni, int nj,
+                        const T* v, int64_t ldv, int k, hipStream_t st) {
   if (k == 1)
-    launch_few_kc<1>(cols, assign, out, ldo, M, ldm, ni, nj, v, ldv, k, st);
+    launch_few_kc<T, 1>(cols, assign, out, ldo, M, ldm, ni, nj, v, ldv, k, st);
   else if (k == 2)
-    launch_few_kc<2>(cols, assign, out, ldo, M, ldm, ni, nj, v, ldv, k, st);
+    launch_few_kc<T, 2>(cols, assign, out, ldo, M, ldm, ni, nj, v, ldv, k, st);
   else
-    launch_few_kc<KMAX>(cols, assign, out, ldo, M, ldm, ni, nj, v, ldv, k, st);
+    launch_few_kc<T, KMAX>(cols, assign, out, ldo, M, ldm, ni, nj, v, ldv, k, st);
 }
+template void launch_few_product<float>(bool, bool, float*, int64_t, const float*, int64_t, int64_t, int, const float*,
+                                        int64_t, int, hipStream_t);
+template void launch_few_product<double>(bool, bool, double*, int64_t, const double*, int64_t, int64_t, int,
+                                         const double*, int64_t, int, hipStream_t);
 
 void launch_f64_to_f32(const double* in, float* out, int64_t count, hipStream_t st) {
   if (count <= 0) return;
