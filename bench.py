@@ -9,7 +9,9 @@ kernel, mean, variance TRSM) on BASELINE.json configs[2] — N=65536, d=3, RBF, 
 M=4096 (M fixed by SURVEY.md §8) — with X, y, Xs already resident in HBM (torch CUDA
 tensors are only the containers; all arithmetic is libgpx.so).
 
-N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU.
+N > 1: one process per GPU, launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``
+(the driver's contract) — or by ``python bench.py --gpus N`` alone: without WORLD_SIZE in the environment this
+file starts that launcher itself, as a child (``launch_ranks``; the parent touches no GPU and exits with its code).
   --mode auto (default) = the graded multi-GPU path of SURVEY.md §8(e): ONE N=65536 Gram
       matrix in row-block-cyclic shards over the ranks, panel broadcast / all-gather over
       RCCL with one-panel look-ahead, value = (N+M) / max-over-ranks time, ``"scaling":
@@ -43,12 +45,12 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                  through the factorisation), a few steps after the timed region; reported beside the headline,
                  never ``value``
   cpu_baseline — the NumPy/SciPy oracle (oracle/gp_oracle.py) on the GPU box's host cores.
-                 ``value`` is the rate AT THE WORKLOAD (N=65536): the full-size oracle run that
-                 also wrote the committed golden fixture (oracle/make_golden_full.py, ~2 min with 16
-                 threads; record under profiles/, or re-measured live with --cpu-baseline-full);
-                 ``live_sample`` is the bounded run of every bench invocation (N=24576, same
-                 generator, ~20 s) with its phase-wise extrapolation as a cross-check.  BLAS threads
-                 = the CPUs the process may use (affinity and cgroup quota) = ``cores``
+                 ``value`` is the rate AT THE WORKLOAD (N=65536), measured IN THIS RUN after the GPU timed
+                 region (oracle/make_golden_full.py in a child: ~2 min with 16 threads, 35 GB of host memory;
+                 ``measured_in_this_run``, ``cores``, ``seconds``).  Hosts with < 40 GB available, or a child that
+                 fails / runs out of time, fall back to the committed record of such a run (profiles/, ``source:
+                 "committed record"``) beside a bounded live sample (N=24576, ~20 s) with its phase-wise
+                 extrapolation.  BLAS threads = the CPUs the process may use (affinity and cgroup quota) = ``cores``
 """
 from __future__ import annotations
 
@@ -147,39 +149,55 @@ def full_size_oracle_record():
     return None
 
 
-def cpu_full_size_live():
-    """--cpu-baseline-full: the oracle at the workload's own size, now, on this host (34.4 GB, minutes)."""
+def host_memory_available_gb():
+    """What this process may still allocate on the host: min(MemAvailable, cgroup limit - usage), GB."""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = float(line.split()[1]) * 1024.0 / 1e9
+    except OSError:
+        pass
+    try:                                            # cgroup v2
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            room = (float(lim) - float(open("/sys/fs/cgroup/memory.current").read())) / 1e9
+            avail = room if avail is None else min(avail, room)
+    except (OSError, ValueError):
+        pass
+    return avail
+
+
+def cpu_full_size_live(timeout_s):
+    """The oracle at the workload's own size, now, on this host (34.4 GB in place, about 2 minutes with 16 threads),
+    in a child process (exact PID kept; killed at `timeout_s`).  Returns (record | None, why-not | None)."""
     import subprocess
     import tempfile
     out = os.path.join(tempfile.gettempdir(), f"gpx_g5_{os.getpid()}.npz")
+    t0 = time.perf_counter()
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_golden_full.py"), "--config", "C3",
-                            "--out", out], capture_output=True, text=True, check=True)
+                            "--out", out], capture_output=True, text=True, timeout=timeout_s)
+        if r.returncode != 0:
+            return None, f"full-size oracle child exited with code {r.returncode}: {r.stderr.strip()[-200:]}"
         rec = json.loads(r.stdout.strip().splitlines()[-1])
-        return {"file": "live (--cpu-baseline-full)", "points_per_s": rec["oracle_points_per_s"],
+        return {"file": "measured in this run", "points_per_s": rec["oracle_points_per_s"],
                 "seconds": rec["oracle_fit_predict_s"], "threads": rec["blas_threads"],
-                "cholesky_s": rec["oracle_cholesky_s"]}
+                "cholesky_s": rec["oracle_cholesky_s"], "kbuild_s": rec["oracle_kbuild_s"],
+                "predict_s": rec["oracle_predict_s"], "wall_s_incl_start": time.perf_counter() - t0}, None
+    except subprocess.TimeoutExpired:
+        return None, f"full-size oracle child did not finish within {timeout_s:.0f} s (killed)"
+    except Exception as e:                           # no JSON line, ...
+        return None, f"full-size oracle child: {type(e).__name__}: {e}"
     finally:
         if os.path.exists(out):
             os.remove(out)
 
 
-def cpu_baseline(n_sample=24576, full_live=False):
-    """`value` = the oracle's fit+predict rate AT THE WORKLOAD (N=65536), measured at full size on a GPU
-    box's host cores (committed record, or live with --cpu-baseline-full); `live_sample` = the bounded
-    run of this invocation (about 10-30 s) and its phase-wise extrapolation, as a cross-check.
-
-    The BLAS pools are limited to the CPUs this process may really use (affinity, cgroup
-    quota): a pool larger than the quota — the default is 64 threads on this pool's hosts
-    whatever the box's share — leaves most workers spinning inside a throttled cgroup and the
-    LAPACK Cholesky crawls (round 1: 30 GF/s with 64 threads against 27 GF/s with one)."""
-    import numpy as np
-    from threadpoolctl import threadpool_info, threadpool_limits
+def cpu_sample(n_sample, threads):
+    """The bounded live sample: the oracle at N = n_sample (same generator), phase-wise extrapolated to the workload."""
+    from threadpoolctl import threadpool_limits
     from oracle.gp_oracle import OracleGP
-    aff, quota, usable = cpu_budget()
-    pools = threadpool_info()
-    blas_max = max((int(p.get("num_threads") or 1) for p in pools if p.get("user_api") == "blas"), default=1)
-    threads = max(1, min(usable, blas_max))
     X, y, Xs = synthetic(n_sample, DIM, M_TEST, 12345)
     with threadpool_limits(limits=threads, user_api="blas"):
         t0 = time.perf_counter()
@@ -192,28 +210,67 @@ def cpu_baseline(n_sample=24576, full_live=False):
     # extrapolate each phase to N=65536 by its algorithmic work
     est = (tm["kbuild"] * r ** 2 + tm["chol"] * r ** 3 + tm["solve"] * r ** 2
            + (tm["kstar"] + tm["mean"]) * r + (tm["trsm"] + tm["var"]) * r ** 2) * 1e-3
-    chol_gf = n_sample ** 3 / 3.0 / (tm["chol"] * 1e-3) / 1e9
-    full = cpu_full_size_live() if full_live else full_size_oracle_record()
-    live = {"N": n_sample, "points_per_s": (n_sample + M_TEST) / (t2 - t0), "fit_s": t1 - t0, "predict_s": t2 - t1,
-            "cholesky_gflops": chol_gf, "threads": threads,
+    return {"N": n_sample, "points_per_s": (n_sample + M_TEST) / (t2 - t0), "fit_s": t1 - t0, "predict_s": t2 - t1,
+            "seconds": t2 - t0, "cholesky_gflops": n_sample ** 3 / 3.0 / (tm["chol"] * 1e-3) / 1e9, "threads": threads,
             "extrapolated_seconds_at_workload": est,
             "extrapolated_points_per_s_at_workload": (N_TRAIN + M_TEST) / est}
+
+
+def cpu_baseline(mode="auto", n_sample=24576, full_timeout_s=420.0):
+    """`value` = the oracle's fit+predict rate AT THE WORKLOAD (N=65536) on THIS host's cores.
+
+    mode "auto" (default): measured IN THIS RUN at full size (the GPU side is finished by then; ~2 min with 16
+      threads, 35 GB of host memory) whenever the host has >= 40 GB available — `measured_in_this_run: true`;
+      otherwise, or if the child fails / exceeds `full_timeout_s`, the committed record of an earlier full-size run
+      on a GPU box (profiles/r*_cpu_full_oracle_c3.json; `source: "committed record"`) beside a bounded live
+      sample (N=24576, ~20 s) of this run.  "full": the same without the memory check.  "record": the committed
+      record + the bounded live sample (the round-3 behaviour).  "sample": the bounded sample alone, extrapolated.
+
+    The BLAS pools are limited to the CPUs this process may really use (affinity, cgroup
+    quota): a pool larger than the quota — the default is 64 threads on this pool's hosts
+    whatever the box's share — leaves most workers spinning inside a throttled cgroup and the
+    LAPACK Cholesky crawls (round 1: 30 GF/s with 64 threads against 27 GF/s with one)."""
+    from threadpoolctl import threadpool_info
+    aff, quota, usable = cpu_budget()
+    pools = threadpool_info()
+    blas_max = max((int(p.get("num_threads") or 1) for p in pools if p.get("user_api") == "blas"), default=1)
+    threads = max(1, min(usable, blas_max))
+    mem_gb = host_memory_available_gb()
+    full = why = None
+    if mode in ("auto", "full"):
+        if mode == "auto" and mem_gb is not None and mem_gb < 40.0:
+            why = f"only {mem_gb:.0f} GB of host memory available (the in-place oracle needs 35 GB)"
+        else:
+            full, why = cpu_full_size_live(full_timeout_s)
+    measured_now = full is not None
+    live = None
+    if not measured_now:                             # the bounded sample: cross-check of a committed record, or the only number
+        live = cpu_sample(n_sample, threads)
+        if mode != "sample":
+            full = full_size_oracle_record()
     if full:
         value, cores = full["points_per_s"], full["threads"] or threads
-        how = (f"FULL workload N={N_TRAIN} d={DIM} M={M_TEST} RBF fp64, same generator, measured once at full size on a "
-               f"GPU box's host with {cores} BLAS threads ({full['file']}: {full['seconds']:.1f} s per fit+predict, "
-               f"Cholesky {full['cholesky_s']:.1f} s); this run's bounded live sample (N={n_sample}, {t2 - t0:.1f} s) "
-               f"extrapolates phase-wise to {(N_TRAIN + M_TEST) / est:.0f} points/s")
+        where = ("measured in this run on this host, after the GPU timed region" if measured_now else
+                 f"measured once at full size on a GPU box's host ({full['file']})")
+        how = (f"FULL workload N={N_TRAIN} d={DIM} M={M_TEST} RBF fp64, same generator, {where}, {cores} BLAS threads: "
+               f"{full['seconds']:.1f} s per fit+predict, Cholesky {full['cholesky_s']:.1f} s")
+        if live:
+            how += (f"; this run's bounded live sample (N={n_sample}, {live['seconds']:.1f} s) extrapolates phase-wise to "
+                    f"{live['extrapolated_points_per_s_at_workload']:.0f} points/s")
     else:
-        value, cores = (N_TRAIN + M_TEST) / est, threads
-        how = (f"no full-size record committed: phase-wise EXTRAPOLATION to N={N_TRAIN} of a live N={n_sample} sample "
-               f"({t2 - t0:.1f} s)")
+        value, cores = live["extrapolated_points_per_s_at_workload"], threads
+        how = (f"phase-wise EXTRAPOLATION to N={N_TRAIN} of a live N={n_sample} sample ({live['seconds']:.1f} s)")
     return {
         "value": value, "unit": "points/s", "cores": cores, "kind": "port",
         "sample": "oracle/gp_oracle.py (NumPy/SciPy; level-3 blocked Cholesky — LAPACK potrf of the bundled OpenBLAS "
                   "does not parallelise): " + how,
-        "at_workload": bool(full), "measured_full_size": full, "live_sample": live,
+        "at_workload": bool(full), "measured_in_this_run": measured_now,
+        "source": "this run" if measured_now else ("committed record" if full else "extrapolated live sample"),
+        "seconds": full["seconds"] if full else live["extrapolated_seconds_at_workload"],
+        "not_measured_live_because": why,
+        "measured_full_size": full, "live_sample": live,
         "host": {"os_cpu_count": os.cpu_count(), "affinity_cpus": aff, "cgroup_cpu_quota": quota,
+                 "memory_available_gb": mem_gb,
                  "blas_pools": [f"{p.get('internal_api')} {p.get('version')}: {p.get('num_threads')} threads by default"
                                 for p in pools if p.get("user_api") == "blas"],
                  "blas_threads_used": threads},
@@ -244,13 +301,20 @@ def main():
                     help="gloo = rehearsal of the multi-rank code on one GPU (host collectives)")
     ap.add_argument("--device", type=int, default=None, help="HIP device override (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="re-measure the full-size (N=65536) CPU oracle live (about 2-3 minutes, 35 GB of host memory)")
+    ap.add_argument("--cpu-baseline", choices=["auto", "full", "record", "sample"], default="auto",
+                    help="auto (default): the full-size (N=65536) CPU oracle measured live after the GPU timed region (about 2 "
+                         "minutes, 35 GB of host memory) when the host has >= 40 GB available, else the committed record + a "
+                         "bounded live sample; full: live without the memory check; record / sample: see cpu_baseline()")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="= --cpu-baseline full (kept from round 3)")
     ap.add_argument("--no-microbench", action="store_true")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Bare launch (`python bench.py --gpus N`, no launcher): start the one-process-per-GPU launcher ourselves,
+        # as a CHILD — this process never touches a GPU — and leave with its exit code.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if args.mode == "auto":
         if world > 1:
             failure = supervise_sharded_child(args, "shard")
@@ -283,6 +347,29 @@ def main():
             sys.exit(1)
         args.mode = "replicas"
     run(args)
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>` as a child
+    (exact PID kept; this process initialises no GPU) and return its exit code.  The ranks then take the same
+    path as under the driver's own launcher: the JSON line is rank 0's."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                 # a port nobody listens on right now
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL between processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env)
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        return child.wait()
 
 
 def beat(args, what):
@@ -611,7 +698,7 @@ def run(args):
         if dtype == "mixed":
             out["refinement"] = {k_: acc[k_] / steps for k_ in ("refine", "refine_iters", "refine_resid0", "refine_resid")}
         if world == 1 and not args.no_cpu_baseline and args.workload == "C3" and N == N_TRAIN:
-            out["cpu_baseline"] = cpu_baseline(full_live=args.cpu_baseline_full)
+            out["cpu_baseline"] = cpu_baseline("full" if args.cpu_baseline_full else args.cpu_baseline)
         if world > 1:
             sync()
         print(json.dumps(out), flush=True)
