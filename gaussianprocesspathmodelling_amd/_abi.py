@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgpx.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 KERNEL_IDS = {"rbf": 0, "matern52": 1}
 DTYPE_IDS = {"float64": 0, "float32": 1, "mixed": 2}
@@ -35,7 +35,7 @@ class GpxTimings(C.Structure):
                  "comm", "chol_diag", "chol_trsm", "chol_strip", "chol_syrk", "syrk_flops")] + \
                [("syrk_launches", C.c_int64), ("kbuild_bytes", C.c_double)] + \
                [(n, C.c_double) for n in ("grad_trtri", "grad_trace", "grad_total", "refine", "refine_resid0",
-                                          "refine_resid", "refine_iters")]
+                                          "refine_resid", "refine_iters", "handover_flags", "handover_retries")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -34,23 +34,29 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit for gfx950 and link libgpx.so."""
+    """Compile every HIP translation unit for gfx950 and link libgpx.so.  Objects older than their source or any
+    shared header are recompiled (all of them with ``force``), a few at a time."""
     if not force and not needs_build():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
-    objs = []
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    objs, jobs = [], []
     for src in SOURCES:
+        path = os.path.join(CSRC, src)
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(path)):
+            jobs.append([hipcc, "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-c", path, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as pool:
+        list(pool.map(run, jobs))
+    run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

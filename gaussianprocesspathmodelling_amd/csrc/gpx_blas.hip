@@ -1058,8 +1058,12 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
 // launches nothing and raises this flag; every API entry point turns it into an error return.
 void set_latency_mode(int on) { g_latency_mode = on; }
 
-static std::atomic<int> g_launch_error{0};
-int take_launch_error() { return g_launch_error.exchange(0); }
+static thread_local int g_launch_error = 0;  // per host thread = per API call in flight (a handle is used by one thread at a time)
+int take_launch_error() {
+  const int e = g_launch_error;
+  g_launch_error = 0;
+  return e;
+}
 
 template <typename T>
 void launch_potf2_64(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st, unsigned* flag,
@@ -1094,7 +1098,7 @@ void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
   // builds ldx from ld_skew<T>(); a violation is a programming error in this library, caught
   // here before a silently stale read can happen.
   if (((uintptr_t)X | (uintptr_t)(ldx * (int64_t)sizeof(T))) % 128 != 0) {
-    g_launch_error.store(1);  // reported by the API call in flight (take_launch_error)
+    g_launch_error = 1;  // reported by the API call in flight (take_launch_error)
     return;
   }
   // few slabs (the diagonal chain, the alpha solves): every product is one latency-bound walk -> KS64 lines
@@ -1112,7 +1116,7 @@ void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv
                        int64_t ldw, hipStream_t st, int phase) {
   debug_delay(st);
   if (((uintptr_t)U | (uintptr_t)(ldu * (int64_t)sizeof(T))) % 128 != 0) {
-    g_launch_error.store(1);
+    g_launch_error = 1;
     return;
   }
   if (phase == 1 && q0 == 0) return;  // nothing lies left of the first block

@@ -73,7 +73,9 @@ void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv
 // barrier — 64 or 128 KB of LDS per workgroup instead of 32 — which shortens every latency-bound K walk
 // when the GPU is otherwise idle and must NOT be used beside a large trailing update (see gpx_blas.hip).
 void set_latency_mode(int on);
-// 1 if a launcher since the last call refused misaligned operands (and launched nothing); clears the flag
+// 1 if a launcher CALLED BY THIS HOST THREAD since the last call refused misaligned operands (and launched nothing);
+// clears the flag.  Thread-local: an API call enqueues and checks on one thread, so a handle only ever sees its own
+// launches' errors (distinct handles on distinct threads: include/gpx.h)
 int take_launch_error();
 // X (rows x nb, ldx) <- X * L^-1 (right, lower, no-transpose; descending blocks).
 template <typename T>
@@ -103,6 +105,9 @@ unsigned launch_gemm_nt_fused(T* C, int64_t ldc, const T* P, int64_t ldp, int64_
 // One wave that returns once *ctr >= target (polled at device scope, ~2 us period).  Bounded: after
 // ~15 s it gives up, sets *info = INT_MIN (the caller reports it) and returns — never a hung queue.
 void launch_wait_counter(const unsigned* ctr, unsigned target, int* info, hipStream_t st);
+// the two halves of the hand-over self-test: *seen = 1 iff the waiting kernel saw *flag != 0 within max_polls x ~2 us
+void launch_flag_probe_wait(const unsigned* flag, unsigned* seen, unsigned max_polls, hipStream_t st);
+void launch_flag_probe_set(unsigned* flag, hipStream_t st);
 // Sharded trailing update: C (m local rows x n, 128-tiles) -= A B^T restricted to tiles with
 //   tile_col <= ((tile_row / tpb) * P + c) * tpb + tile_row % tpb   (block-cyclic rows).
 // test hook: random spin kernels in front of launches (gpx_debug_set_delay; gpx_misc.hip)

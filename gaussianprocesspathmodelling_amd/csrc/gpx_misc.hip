@@ -335,6 +335,24 @@ __global__ void wait_counter_kernel(const unsigned* ctr, unsigned target, int* i
   __threadfence();
 }
 
+// Self-test of the device-flag hand-over (flag_handover_probe, gpx_api.hip): the wait side polls for at most
+// max_polls x ~2 us and reports whether it SAW the flag; the set side publishes it.  Where kernels of different
+// streams do not run concurrently (AMD_SERIALIZE_KERNEL, counter collection, a tool that funnels the streams into
+// one queue) the wait side runs out of polls before the set side starts: seen stays 0.
+__global__ void flag_probe_wait_kernel(const unsigned* flag, unsigned* seen, unsigned max_polls) {
+  if (threadIdx.x == 0) {
+    unsigned polls = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && polls < max_polls) {
+      __builtin_amdgcn_s_sleep(64);
+      ++polls;
+    }
+    *seen = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0 && polls < max_polls ? 1u : 0u;
+  }
+}
+__global__ void flag_probe_set_kernel(unsigned* flag) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void spin_kernel(long long cycles) {
   const long long t0 = __builtin_amdgcn_s_memtime();
   while (__builtin_amdgcn_s_memtime() - t0 < cycles) {
@@ -367,6 +385,13 @@ void launch_copy2d(T* dst, int64_t ldd, const T* src, int64_t lds, int64_t rows,
   const int64_t total = rows * (cols * (int64_t)sizeof(T) / 16);
   const int64_t bx = (total + 255) / 256;
   hipLaunchKernelGGL(copy2d_kernel<T>, dim3((unsigned)(bx > 8192 ? 8192 : bx)), dim3(256), 0, st, dst, ldd, src, lds, rows, cols);
+}
+
+void launch_flag_probe_wait(const unsigned* flag, unsigned* seen, unsigned max_polls, hipStream_t st) {
+  hipLaunchKernelGGL(flag_probe_wait_kernel, dim3(1), dim3(64), 0, st, flag, seen, max_polls);
+}
+void launch_flag_probe_set(unsigned* flag, hipStream_t st) {
+  hipLaunchKernelGGL(flag_probe_set_kernel, dim3(1), dim3(64), 0, st, flag);
 }
 
 void launch_wait_counter(const unsigned* ctr, unsigned target, int* info, hipStream_t st) {

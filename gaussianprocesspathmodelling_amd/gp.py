@@ -257,7 +257,7 @@ class GP:
         pq, kq, keepq, devq, sq = self._as_input(Xs, "Xs")
         px, kx, keepx, devx, sx = self._as_input(X, "X")
         py, ky, keepy, devy, sy = self._as_input(y, "y")
-        if not fused or len(sq) != 2 or sq[0] > 8192 or not (kx == ky == kq):
+        if not fused or len(sq) != 2 or not (kx == ky == kq):
             mean, var = self.fit(X, y).predict(Xs, include_noise=include_noise)
             return mean, var
         if len(sx) != 2:
@@ -292,6 +292,10 @@ class GP:
         for _ in range(max(1, self.max_tries)):
             rc = self._lib.gpx_fit_predict(self._h, px, py, N, d, k, _abi.dptr(ls), ls.size, self.variance, self.noise,
                                            jitter, pq, M, pm, pv, kx, C.byref(info))
+            if rc in (_abi.E_UNSUPPORTED, _abi.E_NOMEM):
+                # the library's own limits decide (its batch cap honours GPX_PRED_BATCH; M more bordered rows of K and
+                # of the panel buffers may not fit beside the factor): the documented fallback is the two calls
+                return self.fit(X, y).predict(Xs, include_noise=include_noise)
             self._check(rc)
             self.info_ = int(info.value)
             if self.info_ == 0:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GPX_ABI_VERSION 4 /* v4: + gpx_fit_predict (v3: gpx_set_flags, refine semantics, one-rank groups) */
+#define GPX_ABI_VERSION 5 /* v5: gpx_timings.handover_*, fp32 / mixed shards; v4: + gpx_fit_predict (v3: gpx_set_flags, refine, one-rank groups) */
 
 /* kernel family — SURVEY.md §8 row a1 (nearest reference code: the pairwise
  * distance loop trajectories.calc_distance, GPmap.py:114-121, and the unused
@@ -104,6 +104,12 @@ typedef struct gpx_timings {
   double refine;                           /* GPX_MIXED: ms spent refining alpha in fp64 */
   double refine_resid0, refine_resid;      /* ||y - K alpha|| / ||y|| before / after the refinement */
   double refine_iters;                     /* GPX_MIXED: refinement iterations the last fit ran */
+  /* ABI v5: how the streams of the last fit handed over inside the diagonal chain.  1 = device flags (a kernel parked  \
+     on the side stream polls a word the POTF2 publishes), 0 = hipEvents — chosen by a ~100 us self-test at the handle's \
+     first fit (does a parked kernel see a store launched later on another stream?), by GPX_CHAIN_FLAG=0|1, or because    \
+     rocprofv3 counter collection is on.  Same kernels and bit-identical results either way. */
+  double handover_flags;
+  double handover_retries;                 /* fits of this handle re-run with hipEvents after a parked stream timed out */
 } gpx_timings;
 
 /* ---- lifecycle ------------------------------------------------------------- */
