@@ -956,6 +956,10 @@ int64_t pred_batch_rows(gpx_handle* h, int64_t Mpad, size_t row_bytes, bool may_
 
 template <typename T>
 int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_t mem_kind);
+bool few_solver_applies(const gpx_handle* h);
+template <typename T>
+int solve_few(gpx_handle* h, T* RT, int k, const T* L, int64_t ld, int64_t n, const T* W, int nb, bool forward = true,
+              bool backward = true);
 
 }  // namespace
 
@@ -1093,7 +1097,7 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
 // RT (k <= 8 rows of ld) <- (L L^T)^-1 RT (or only L^-T RT) with the fit's explicit block inverses: a forward and a
 // backward block substitution as streams over the factor (gpx_mixed.hip: rowdot / coldot kernels), one stream, in order.
 template <typename T>
-int solve_few(gpx_handle* h, T* RT, int k, const T* L, int64_t ld, int64_t n, const T* W, int nb, bool forward = true) {
+int solve_few(gpx_handle* h, T* RT, int k, const T* L, int64_t ld, int64_t n, const T* W, int nb, bool forward, bool backward) {
   int rc;
   if ((rc = ensure(h, h->Zfew, (size_t)8 * nb * sizeof(T)))) return rc;
   T* Zs = (T*)h->Zfew.p;
@@ -1106,7 +1110,7 @@ int solve_few(gpx_handle* h, T* RT, int k, const T* L, int64_t ld, int64_t n, co
                                hipMemcpyDeviceToDevice, st));
     launch_few_product<T>(false, false, RT + t0, ld, L + t0 * ld + o, ld, n - t0, nbp, Zs, nb, k, st);
   }
-  for (int64_t o = ((n - 1) / nb) * nb; o >= 0; o -= nb) {  // L^T x = z
+  for (int64_t o = ((n - 1) / nb) * nb; backward && o >= 0; o -= nb) {  // L^T x = z
     const int nbp = (int)std::min<int64_t>(nb, n - o);
     launch_few_product<T>(true, true, Zs, nb, W + (o / nb) * (int64_t)nb * nb, nb, nbp, nbp, RT + o, ld, k, st);
     HIPCHK(h, hipMemcpy2DAsync(RT + o, (size_t)ld * sizeof(T), Zs, (size_t)nb * sizeof(T), (size_t)nbp * sizeof(T), k,
@@ -1116,12 +1120,13 @@ int solve_few(gpx_handle* h, T* RT, int k, const T* L, int64_t ld, int64_t n, co
   return GPX_OK;
 }
 
-// the streaming solver needs the fit's explicit block inverses, at most 8 right-hand sides and blocks <= 1024 wide
-// (GPX_FEW_SOLVE=0: always the slab path)
+// the streaming solver needs the fit's explicit block inverses (h->Wblk, blocks of width h->nbw <= 1024: every block of
+// an unsharded fit, or of a shard that keeps the whole factor), at most 8 right-hand sides (GPX_FEW_SOLVE=0: always the
+// slab path)
 bool few_solver_applies(const gpx_handle* h) {
   const char* e = getenv("GPX_FEW_SOLVE");
-  return (!e || atoi(e) != 0) && h->nbw > 0 && h->nbw == h->nb && h->nb <= 1024 && h->nb % 128 == 0 && h->k <= 8 &&
-         !h->comm && h->Wblk.p;
+  return (!e || atoi(e) != 0) && h->nbw > 0 && h->nbw <= 1024 && h->nbw % 128 == 0 && h->k <= 8 &&
+         (!h->comm || h->repl) && h->Wblk.p;
 }
 
 // alpha^T = z^T L^-1 on a copy of the bordered rows (z stays available for V^T z)
@@ -1167,7 +1172,7 @@ int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_
   if ((rc = ensure(h, h->meanout, (size_t)M * k * sizeof(T)))) return rc;
   if ((rc = ensure(h, h->var, (size_t)Mpad * sizeof(T)))) return rc;
   SolveWork<T> sw;
-  if (want_var && h->nbw == h->nb_pred && !h->comm) {  // block inverses of this fit, same block width
+  if (want_var && h->nbw == h->nb_pred && (!h->comm || h->repl)) {  // block inverses of this fit (a shard: of the factor it keeps whole), same block width
     sw.ldt = h->nbw + ld_skew<T>();
     if ((rc = ensure(h, h->Tsol, (size_t)2 * MB * sw.ldt * sizeof(T)))) return rc;
     sw.W = (const T*)h->Wblk.p;

@@ -37,6 +37,7 @@ def run(N, M, kw, grad):
     (2600, 200, {"devices": 3, "oversubscribe": True}, False, True),    # device group, distributed solves
     (2600, 200, {"devices": 4, "oversubscribe": True}, True, True),     # device group, replicated factor + sharded gradient
     (9000, 300, {"devices": 2, "oversubscribe": True}, False, False),   # device group, library-chosen 1024-blocks
+    (5200, 200, {"devices": 8, "oversubscribe": True}, False, True),    # eight ranks, 21 panels of 256: the split schedule's hand-overs
     (9000, 300, {"device": 0, "world": 1, "rank": 0, "comm": "rccl"}, False, False),   # RCCL calls on two streams
     (9000, 300, {"devices": [0], "transport": "rccl"}, False, False),   # the same through ncclCommInitAll (one-rank group)
 ])

@@ -293,3 +293,56 @@ def test_c4_shape_group_world4_n65536_overlapped():
     resid = c4_checks([r], N, M, single_gpu_c4(N, M))
     print(f"C4 shape, 4 ranks in one process, N={N}: residual {resid:.2e}, fit {tm['fit_total']:.0f} ms "
           f"(chol {tm['chol']:.0f} ms, comm {tm['comm']:.0f} ms), predict {tm['predict_total']:.0f} ms")
+
+
+def test_c4_real_shape_world8_nb1024_n131072():
+    """BASELINE.json configs[3] at the per-rank SHAPE it really has: P = 8 ranks x library-chosen
+    nb = 1024, Matern-5/2, distributed solves, 16 panels per rank — N = 131072 (137 GB, what one card holds; C4 itself is
+    N = 262144 on eight cards with 32 panels per rank), the eight ranks threads of this process sharing the one GPU.
+    Checks of SURVEY.md §8(d) for C4 incl. agreement with the unsharded path at 1e-10 (run after the group is gone:
+    137 GB each).  No hardware with eight cards has run this: the transport here is same-device copies."""
+    N, M = 131072, 1024
+    import os
+    os.environ["GPX_SHARD_REPLICATE"] = "0"
+    os.environ.pop("GPX_NB_SHARD", None)
+    try:
+        with GP(jitter=0.0, devices=[0] * 8, **C4) as gp:
+            r = c4_run(gp, N, M)
+            tm = gp.timings_
+    finally:
+        os.environ.pop("GPX_SHARD_REPLICATE", None)
+    resid = c4_checks([r], N, M, single_gpu_c4(N, M))
+    print(f"C4 real shape (P = 8 x nb = 1024), N={N} on one card: residual {resid:.2e}, fit {tm['fit_total']:.0f} ms "
+          f"(chol {tm['chol']:.0f} ms, comm {tm['comm']:.0f} ms), predict {tm['predict_total']:.0f} ms")
+
+
+@pytest.mark.parametrize("ndev,N,nb,repl", [(3, 4000, 256, 0), (4, 4000, 256, 1), (2, 9000, 0, 1), (8, 6000, 128, 0)])
+def test_group_split_schedule_is_bit_identical_to_the_round3_schedule(monkeypatch, ndev, N, nb, repl):
+    """The sharded factorisation's round-4 schedule (only the next diagonal block on the chain, the rows below it and
+    the REST on the main stream, early hand-over of the REST's first column block) against the round-3 one
+    (GPX_SPLIT_STRIP=0: whole strip, then the chain) and against a REST that is never / always split
+    (GPX_REST_SPLIT): the same arithmetic per element in the same order — every output bit-identical."""
+    if nb:
+        monkeypatch.setenv("GPX_NB_SHARD", str(nb))
+    else:
+        monkeypatch.delenv("GPX_NB_SHARD", raising=False)
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", str(repl))
+    X, y, Xs = synthetic_problem(N, 3, 300, seed=N + ndev)
+
+    def run():
+        with GP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0, devices=ndev, oversubscribe=True) as gp:
+            mean, var = gp.fit(X, y).predict(Xs)
+            return mean, var, gp.alpha_.copy(), gp.log_det_
+
+    base = run()
+    ref = OracleGP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    check(base[0], base[1], base[2], base[3], ref, mr, vr)
+    for env in ({"GPX_SPLIT_STRIP": "0"}, {"GPX_REST_SPLIT": "0"}, {"GPX_REST_SPLIT": "1"}, {"GPX_REST_SPLIT": "1000"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        got = run()
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        for a, b in zip(base, got):
+            assert np.array_equal(a, b), env
