@@ -76,7 +76,6 @@ struct gpx_handle {
   int nb_pred = 1024;  // block width of the variance TRSM
   hipStream_t st = nullptr;   // main stream
   hipStream_t st2 = nullptr;  // look-ahead (panel) stream, high priority
-  hipStream_t stm = nullptr;  // main stream with a CU mask (GPX_CU_RESERVE CUs left to the chain); null: none
   hipStream_t st3 = nullptr;  // side stream of the diagonal chain: in-block SYRKs, block inverses
   hipStream_t st4 = nullptr;  // copy stream: solved panels / blocks back into their matrices
   std::string err;
@@ -106,6 +105,7 @@ struct gpx_handle {
   DevBuf Tsol;       // predict: compact solved blocks of V^T (2 x batch x (nb + skew))
   DevBuf MTpart;         // split-K partial tiles of the posterior-mean product
   DevBuf ZTloc, ZTpack;  // sharded gradient: own row blocks of L^-T (stacked), one packed block in flight
+  DevBuf resv_ring;  // device counters of the self-reserving trailing updates ([1024][8] unsigned; GPX_CU_SELF_RESERVE)
   DevBuf Wblk, Ublk; // explicit inverses of the nb x nb diagonal blocks of L ([Npad/nb][nb][nb]) + scratch
   int nbw = 0;       // block width of Wblk (0: not built)
   int nb_shard = 512;  // distribution block = panel width of the sharded factorisation (chosen per fit)
@@ -300,6 +300,10 @@ bool chain_flag_enabled(const gpx_handle* h) {
 struct LatencyGuard {  // set_latency_mode(0) on every exit path of a scheduler function
   ~LatencyGuard() { set_latency_mode(0); }
 };
+struct ReserveGuard {  // reserve mode off on every exit path of chol_enqueue
+  ~ReserveGuard() { reserve_ring(nullptr, 0); }
+};
+constexpr int RESV_RING = 1024;  // self-reserving launches per factorisation (more: plain kernels)
 
 // ---- blocked right-looking Cholesky, in place on the lower triangle -------------------
 // A [n][ld]; Winv [n/64][64*64]; P = two compact panel buffers [n][ldp]; n multiple of
@@ -581,6 +585,19 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
   };
   LatencyGuard latency_guard;
   set_latency_mode(1);  // panel 0: nothing runs beside it
+  // GPX_CU_SELF_RESERVE = k (round 4): where the chain sets the pace, the main stream's products leave k CUs per XCD to it
+  // by themselves (gemm_nt_resv_kernel: persistent grids that exit on the reserved CUs).  Split schedule only.
+  const int resv_k = [] {
+    const char* e = getenv("GPX_CU_SELF_RESERVE");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 && v <= 4 ? v : 0;
+  }();
+  ReserveGuard reserve_guard;
+  if (resv_k > 0 && split_env) {
+    if ((rc = ensure(h, h->resv_ring, (size_t)RESV_RING * 8 * sizeof(unsigned)))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->resv_ring.p, 0, (size_t)RESV_RING * 8 * sizeof(unsigned), s0));
+    reserve_ring((unsigned*)h->resv_ring.p, RESV_RING);
+  }
   const bool any_fused = is_fused(0);
   if (any_fused) HIPCHK(h, hipMemsetAsync(ctr, 0, sizeof(unsigned), s0));
   // prologue: panel 0 on the main stream
@@ -602,7 +619,6 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       HIPCHK(h, hipStreamWaitEvent(s1, e_init, 0));  // counter reset + panel 0 before the parked stream's first poll
     }
   }
-  hipStream_t cur_main = s0;
   hipEvent_t e_main = nullptr;  // split strip: "the main stream's work on the trailing matrix so far is complete"
   if (split_env && n > nb) {
     e_main = next_event(h);
@@ -615,7 +631,7 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     const int64_t t0 = o + nbp;          // first trailing row/col
     const int64_t ntrail = n - t0;
     if (ntrail <= 0) {  // the last panel: nothing to update, but the side rows still take their solve
-      if ((rc = side_solve(o, Pbuf[step & 1], cur_main))) return rc;
+      if ((rc = side_solve(o, Pbuf[step & 1], s0))) return rc;
       break;
     }
     T* Pc = Pbuf[step & 1];              // panel of this step, rows [t0, n + nx)
@@ -649,15 +665,9 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       continue;
     }
     if (split_env) {
-      // the main stream of this iteration: the CU-masked one once the chain sets the pace (GPX_CU_RESERVE)
-      hipStream_t sm = (h->stm && ntrail <= (int64_t)(rest_split + 1) * nb) ? h->stm : s0;
-      if (sm != cur_main) {  // everything queued on the old one first (stream order carries the buffer hazards)
-        hipEvent_t e_sw = next_event(h);
-        if (!e_sw) return fail(h, GPX_E_HIP, "hipEventCreate failed (stream switch)");
-        HIPCHK(h, hipEventRecord(e_sw, cur_main));
-        HIPCHK(h, hipStreamWaitEvent(sm, e_sw, 0));
-        cur_main = sm;
-      }
+      hipStream_t sm = s0;
+      // self-reserving main-stream products where the chain sets the pace (the criterion of the REST's early hand-over)
+      const int resv_it = (resv_k > 0 && ntrail <= (int64_t)(rest_split + 1) * nb) ? resv_k : 0;
       // SPLIT STRIP (round 3, the default): of the strip only the next DIAGONAL block is on the chain.  It is
       // updated on the look-ahead stream itself, right behind the panel solve that produced its operand (no
       // hand-over between streams on the chain; 64-tiles in latency mode: a K = nb walk of a 64-tile is a
@@ -672,6 +682,7 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       // The host enqueues the main stream's whole iteration BEFORE the diagonal chain's ~50 small launches: the
       // GPU runs the chain about as fast as the host can enqueue it (N = 8192: the update used to reach the GPU
       // 0.5 ms after the panel it needs, and then collided with the NEXT panel solve and diagonal-block update).
+      set_reserve_mode(resv_it);  // everything the main stream runs beside the next diagonal chain
       {  // rows below the diagonal block in the next panel's columns; the chain's bordered rows in a small launch
         PhaseScope ps(h, &h->tm.chol_strip, profile, sm);
         if (nrest > 0)
@@ -723,9 +734,17 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
         if ((rc = side_solve(o, Pc, sm))) return rc;
         bordered_block(o, Pc, sm, t0, ntrail, nxc, nxs);
       }
+      set_reserve_mode(0);
       {
         PhaseScope ps(h, &h->tm.chol_diag, profile, s1);
-        if ((rc = diag_enqueue(h, A, ld, t0, nbn, Winv, info, gidx0, s1, iw))) return rc;
+        static const int chain_env = [] {  // GPX_RESV_CHAIN: 0 chain untouched, 1 (default) POTF2 padded to 130 KB of LDS, 2 also its slab launches
+          const char* e = getenv("GPX_RESV_CHAIN");
+          return e ? atoi(e) : 1;
+        }();
+        set_reserve_chain(resv_it > 0 ? chain_env : 0);
+        rc = diag_enqueue(h, A, ld, t0, nbn, Winv, info, gidx0, s1, iw);
+        set_reserve_chain(0);
+        if (rc) return rc;
       }
       HIPCHK(h, hipStreamWaitEvent(s1, e_below, 0));
       // Panel solve p+1: only the rows of the NEXT diagonal block (what STRIP_D(p+1) and the B operands need) on the
@@ -747,9 +766,11 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       HIPCHK(h, hipStreamWaitEvent(sm, e_panel, 0));
       if (top < nrest || (iw && top_env)) {
         PhaseScope ps(h, &h->tm.chol_trsm, profile, sm);
-        if ((rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest - top, nxc, Winv, Pn, ldp, sm, iw, (step + 1) & 1, top,
-                                      prev_copied, true)))
-          return rc;
+        set_reserve_mode(resv_it);  // runs beside the NEXT diagonal chain
+        rc = panel_solve_enqueue(h, A, ld, t0, nbn, nrest - top, nxc, Winv, Pn, ldp, sm, iw, (step + 1) & 1, top, prev_copied,
+                                 true);
+        set_reserve_mode(0);
+        if (rc) return rc;
       }
       continue;
     }
@@ -792,12 +813,6 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
       }
     }
     HIPCHK(h, hipStreamWaitEvent(s0, e_panel, 0));
-  }
-  if (cur_main != s0) {
-    hipEvent_t e = next_event(h);
-    if (!e) return fail(h, GPX_E_HIP, "hipEventCreate failed (join)");
-    HIPCHK(h, hipEventRecord(e, cur_main));
-    HIPCHK(h, hipStreamWaitEvent(s0, e, 0));
   }
   if (iw) {  // join the side and copy streams: the last inverse and every panel copy-back are in W / A
     for (hipStream_t sj : {iw->aux, h->st4}) {
@@ -1673,22 +1688,6 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) try {
     delete h;
     return fail(nullptr, GPX_E_HIP, "gpx_create: hipSetDevice/hipStreamCreate failed");
   }
-  // GPX_CU_RESERVE = k: the trailing updates of the chain-bound panels run on a stream whose CU mask leaves
-  // k CUs (mask bits 0 .. k-1: one per XCD, round robin) to the look-ahead chain (tools/cumask_probe.hip)
-  if (const char* e = getenv("GPX_CU_RESERVE")) {
-    int ncu = 0;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-    const int k = atoi(e);
-    if (k > 0 && k < ncu) {
-      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0xffffffffu);
-      if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1;
-      for (int b = 0; b < k; ++b) mask[b / 32] &= ~(1u << (b % 32));
-      if (hipExtStreamCreateWithCUMask(&h->stm, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
-        h->stm = nullptr;
-        (void)hipGetLastError();
-      }
-    }
-  }
   *out = h;
   return GPX_OK;
 }
@@ -1706,12 +1705,11 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st2) (void)hipStreamSynchronize(h->st2);
   if (h->st3) (void)hipStreamSynchronize(h->st3);
   if (h->st4) (void)hipStreamSynchronize(h->st4);
-  if (h->stm) (void)hipStreamSynchronize(h->stm);
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->MTpart, &h->var, &h->meanout, &h->G, &h->Pglob,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
                     &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->ZTloc, &h->ZTpack, &h->gpart, &h->Wblk, &h->Ublk, &h->Tsol, &h->X64, &h->Y64, &h->Xs64,
-                    &h->A64, &h->Aprev, &h->R64, &h->X32, &h->Y32, &h->RT32, &h->Q64, &h->Qs64, &h->Q32, &h->M64, &h->rn, &h->Zfew})
+                    &h->A64, &h->Aprev, &h->R64, &h->resv_ring, &h->X32, &h->Y32, &h->RT32, &h->Q64, &h->Qs64, &h->Q32, &h->M64, &h->rn, &h->Zfew})
     release(*b);
   destroy_comm(h);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
@@ -1719,7 +1717,6 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st2) (void)hipStreamDestroy(h->st2);
   if (h->st3) (void)hipStreamDestroy(h->st3);
   if (h->st4) (void)hipStreamDestroy(h->st4);
-  if (h->stm) (void)hipStreamDestroy(h->stm);
   delete h;
 }
 
@@ -1901,6 +1898,7 @@ struct Scratch {  // a throw-away handle-like context for the host-buffer entry 
         (void)hipStreamDestroy(s);
       }
     for (auto e : h.ev_pool) (void)hipEventDestroy(e);
+    release(h.resv_ring);
   }
 };
 #define TCHK(call)                                   \
@@ -2209,7 +2207,7 @@ int gpx_debug_set_delay(uint64_t seed) {
 
 int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t tpb, int32_t c, int32_t* out,
                        int64_t cap, int64_t* count) try {
-  if (!out || !count || tm <= 0 || cap <= 0 || kind < 0 || kind > 3) return GPX_E_ARG;
+  if (!out || !count || tm <= 0 || cap <= 0 || kind < 0 || kind > 2) return GPX_E_ARG;
   if (kind == 1 && (tn <= 0 || P <= 0 || tpb <= 0 || c < 0)) return GPX_E_ARG;
   const int64_t n = debug_tile_map(kind, tm, tn, P, tpb, c, out, cap);
   if (n < 0) return GPX_E_ARG;

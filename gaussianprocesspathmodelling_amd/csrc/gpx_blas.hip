@@ -259,6 +259,101 @@ __global__ __launch_bounds__(256, (BT == 64 && KSUB >= 4) ? 1 : 2) void gemm_nt_
   }
 }
 
+// ---- SELF-RESERVING trailing update (round 4) ---------------------------
+// Where the diagonal chain sets the pace (N = 8192: every panel; the tail of N = 65536) its one-workgroup kernels
+// share CUs with MFMA-saturated update workgroups and run 4-6x slower in every phase — the POTF2's fp64 vector
+// FMAs share the SIMD's double-precision pipe with the co-resident MFMAs (profiles/r03_cu_reserve_experiments.txt).
+// A CU-masked queue gives the chain CUs of its own but costs the update 13 % by itself (same record).  So the
+// update leaves CUs alone BY ITSELF: the launch is a persistent grid — about as many workgroups as the chip has
+// slots — and every workgroup first reads which CU it landed on (HW_REG_HW_ID): on a RESERVED CU (CU 0 of shader
+// engines 0..k-1 of its XCD: k CUs per XCD, 8 k of 256) it exits at once; elsewhere it loops, taking block ids of
+// the static launch's numbering from a device counter — its own XCD's ids first (b = x, x + 8, ...: the same
+// contiguous chunk of the logical tile order the static launch would give that XCD, so the L2 sharing survives),
+// then the other XCDs' leftovers.  The POTF2 (79 KB of LDS) then only fits on a reserved CU: the others hold two
+// 64 KB update workgroups.  Arithmetic per tile is that of the static launch: bit-identical.
+__device__ __forceinline__ bool on_reserved_cu(int resv) {
+  unsigned hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  return ((hw >> 8) & 0xfu) == 0u && (int)((hw >> 13) & 0x7u) < resv;  // CU_ID [11:8], SE_ID [15:13]
+}
+
+// next block id for the calling workgroup (thread 0 only): -1 when every counter has run past `total`
+__device__ __forceinline__ int resv_take(unsigned* ctr, unsigned total, unsigned x0) {
+#pragma unroll 1
+  for (unsigned s = 0; s < 8u; ++s) {
+    const unsigned x = (x0 + s) & 7u;
+    if (x >= total) continue;
+    const unsigned t = atomicAdd(&ctr[x], 1u);
+    const unsigned long long b = 8ull * t + x;
+    if (b < total) return (int)b;
+  }
+  return -1;
+}
+
+template <typename T, int BT, bool TRI, int MODE, int KSUB = 1>
+__global__ __launch_bounds__(256, (BT == 64 && KSUB >= 4) ? 1 : 2) void gemm_nt_resv_kernel(
+    T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
+    int64_t ldb, int tiles_m, int tiles_n, int sh, int mask_lower, int K, unsigned total, unsigned* __restrict__ ctr,
+    int resv, unsigned sweep0) {
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT, KSUB>::SMEM_ELEMS];
+  __shared__ int next_bid;
+  // the LAST workgroup of the grid never leaves for a reservation: whatever the placement, somebody finishes the tiles
+  if (blockIdx.x + 1 != gridDim.x && on_reserved_cu(resv)) return;
+  const bool sweeper = blockIdx.x >= sweep0;  // loops until the counters run out; the others take ONE tile and give the slot back
+  bool done_one = false;
+#pragma unroll 1
+  for (;;) {
+    if (done_one && !sweeper) return;
+    if (threadIdx.x == 0) next_bid = resv_take(ctr, total, blockIdx.x & 7u);
+    __syncthreads();
+    const int bid = next_bid;
+    __syncthreads();  // everybody has read it before thread 0 writes the next one
+    if (bid < 0) return;
+    int ti, tj;
+    if (!tile_coords<TRI>(xcd_chunk_id(bid, total), tiles_m, tiles_n, sh, mask_lower, BcMask{0, 1, 0}, ti, tj)) continue;
+    typename Num<T>::v4 acc[BT / 32][BT / 32];
+    zero_acc(acc);
+    gemm_tile_g<T, BT, BT, 2, KSUB>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc, smem);
+    store_tile<T, BT, BT, MODE>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
+    done_one = true;
+  }
+}
+
+// the same for C = A W^T with W lower triangular (gemm_nt_ltri_kernel: the rows of a panel solve the main stream takes)
+template <typename T, int BT, int KSUB = 1>
+__global__ __launch_bounds__(256, (BT == 64 && KSUB >= 4) ? 1 : 2) void gemm_nt_ltri_resv_kernel(
+    T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw,
+    int tiles_m, int tiles_n, int sh, int K, unsigned total, unsigned* __restrict__ ctr, int resv, unsigned sweep0) {
+  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, BT, BT, KSUB>::SMEM_ELEMS];
+  __shared__ int next_bid;
+  if (blockIdx.x + 1 != gridDim.x && on_reserved_cu(resv)) return;
+  const bool sweeper = blockIdx.x >= sweep0;
+  bool done_one = false;
+  const int half = (tiles_n + 1) >> 1;
+#pragma unroll 1
+  for (;;) {
+    if (done_one && !sweeper) return;
+    if (threadIdx.x == 0) next_bid = resv_take(ctr, total, blockIdx.x & 7u);
+    __syncthreads();
+    const int bid = next_bid;
+    __syncthreads();
+    if (bid < 0) return;
+    int ti, tp;
+    if (!tile_coords<false>(xcd_chunk_id(bid, total), tiles_m, half, sh, 0, BcMask{0, 1, 0}, ti, tp)) continue;
+    const T* At = A + (int64_t)ti * BT * lda;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const int tj = pass == 0 ? tiles_n - 1 - tp : tp;
+      if (pass == 1 && tj == tiles_n - 1 - tp) break;
+      typename Num<T>::v4 acc[BT / 32][BT / 32];
+      zero_acc(acc);
+      gemm_tile_g<T, BT, BT, 2, KSUB>(At, lda, W + (int64_t)tj * BT * ldw, ldw, min(K, (tj + 1) * BT), acc, smem);
+      store_tile<T, BT, BT, 1>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
+    }
+    done_one = true;
+  }
+}
+
 // ---- the sharded trailing update: C -= A * B^T under the block-cyclic row map ----------
 // Local tile row ti stands for global tile row lim(ti) = ((ti/tpb)*P + c)*tpb + ti%tpb of the
 // trailing matrix and owns the tiles tj <= lim(ti): a staircase.  Launching the bounding
@@ -374,47 +469,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(T* __restrict__ C, i
     for (int q = 1; q < S; ++q) v += part[q * pstride + r * ldp + c];
     C[r * ldc + c] = v;
   }
-}
-
-// ---- experimental 256x128 tile, 8 waves (4 x 2, each 64x64): one workgroup per CU ------------
-// Lower triangle of C (m == n, multiples of 256) -= A A^T-style NT product.  Tile row ti (256
-// rows) owns tile columns tj <= 2 ti + 1 (128 wide): the staircase map with P = 2, tpb = 1,
-// c = 1; the part of a straddling tile above the diagonal lands in the never-read upper triangle.
-// Same per-wave work as the 128x128 engine at 25 % fewer LDS-DMA bytes per flop, but all eight
-// waves of a CU now share one barrier.  Selected by GPX_SYRK_TALL=1 (A/B measurement only).
-template <typename T, int MODE>
-__global__ __launch_bounds__(512, 2) void gemm_nt_tall_kernel(
-    T* __restrict__ C, int64_t ldc, const T* __restrict__ A, int64_t lda, const T* __restrict__ B,
-    int64_t ldb, int tiles_m, int tiles_n, BcMask bc, int K, StairMap map) {
-  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 256, 128>::SMEM_ELEMS];
-  const unsigned lin = (unsigned)__builtin_amdgcn_readfirstlane((int)xcd_chunk_id(blockIdx.x, gridDim.x));
-  int ti, tj;
-  stair_coords(map, bc, lin, tiles_m, tiles_n, ti, tj);
-  if (ti >= tiles_m || tj >= tiles_n) return;
-  typename Num<T>::v4 acc[4][4];
-  zero_acc(acc);
-  gemm_tile_g<T, 256, 128, 4>(A + (int64_t)ti * 256 * lda, lda, B + (int64_t)tj * 128 * ldb, ldb, K, acc, smem);
-  store_tile<T, 256, 128, MODE, 4>(C + (int64_t)ti * 256 * ldc + (int64_t)tj * 128, ldc, acc);
-}
-
-// ---- experimental (round 3): 128x128 tile, EIGHT waves (4 x 2, each 32 x 64), TWO k-steps per barrier --
-// The "BK = 64" variant of the fp32 engine (DESIGN.md §8.4 of round 2): a stage holds two 128-byte
-// lines per row (2 x 2 x 256 rows x 128 B = 128 KB of LDS), so one workgroup of eight waves per CU
-// (two waves per SIMD as before), half the barriers per flop and one barrier for all eight waves.
-// Same triangular tile map as gemm_nt_kernel<.., 128, true, ..>.  Selected by GPX_SYRK_W8=1 for the
-// trailing update (A/B measurement only; K must be a multiple of 2 BK).
-template <typename T, int MODE>
-__global__ __launch_bounds__(512) void gemm_nt_w8_kernel(T* __restrict__ C, int64_t ldc, const T* __restrict__ A,
-                                                         int64_t lda, const T* __restrict__ B, int64_t ldb,
-                                                         int tiles_m, int tiles_n, int K) {
-  __shared__ __attribute__((aligned(16))) T smem[TileShapeG<T, 128, 128, 2>::SMEM_ELEMS];
-  const int64_t lin = xcd_chunk_id(blockIdx.x, gridDim.x);
-  int ti, tj;
-  if (!tile_coords<true>(lin, tiles_m, tiles_n, 8, 0, BcMask{0, 1, 0}, ti, tj)) return;
-  typename Num<T>::v4 acc[2][4];
-  zero_acc(acc);
-  gemm_tile_g<T, 128, 128, 4, 2>(A + (int64_t)ti * 128 * lda, lda, B + (int64_t)tj * 128 * ldb, ldb, K, acc, smem);
-  store_tile<T, 128, 128, MODE, 4>(C + (int64_t)ti * 128 * ldc + (int64_t)tj * 128, ldc, acc);
 }
 
 // ---- C -= A * B, B stored [k][n]; 64x64 tiles --------------------------------------
@@ -977,6 +1031,15 @@ int64_t rect_grid(int64_t tm, int64_t tn, int& sh) {
 // see launch_gemm_nt_t: several k-steps per barrier for 64-tile launches, only when the caller says that
 // nothing large runs beside them (per host thread: a handle is driven by one thread at a time)
 thread_local int g_latency_mode = 0;
+// reserve mode of the calling host thread (set_reserve_mode): k > 0 — the launches of launch_gemm_nt go out in their
+// self-reserving form, each with 8 zeroed device counters of its own out of the caller's ring
+struct ReserveState {
+  int k = 0;
+  unsigned* ring = nullptr;  // [cap][8] counters, zeroed by the caller before the first launch of a fit
+  int cap = 0, used = 0;
+  int chain = 0;             // narrow slab launches of the chain ask for a whole CU's worth of LDS (see launch_trsm_rlt)
+};
+thread_local ReserveState g_resv;
 
 inline int cu_count() {
   static const int n = [] {
@@ -1013,28 +1076,78 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
     if (live <= 4 * cu_count() && k % (2 * Num<T>::BK) == 0) ks = 2;
     if (Num<T>::KS64 == 4 && live <= cu_count() && k % (4 * Num<T>::BK) == 0) ks = 4;
   }
-#define GPX_NT_LAUNCH(TRI_, MODE_, ...)                                                                                        \
+  // self-reserving form?  (block-cyclic masks never: the sharded update has its own kernel)
+  unsigned* rctr = nullptr;
+  if (g_resv.k > 0 && bc.P == 0 && lower != 3 && g_resv.used < g_resv.cap) rctr = g_resv.ring + 8 * (size_t)g_resv.used++;
+  // persistent grid: the chip's slots for this kernel (two 64 KB workgroups per CU; 64-tiles: up to four) plus what
+  // the reserved CUs burn (their workgroups exit at once and the dispatcher refills those slots)
+  // Two forms (GPX_RESV_FORM).  1, "turnover" (default): one tile per workgroup as in the static launch — slots keep
+  // turning over, so the chain's wide launches (strip of the next diagonal block, panel product: hundreds of
+  // workgroups) find room everywhere as before — plus a margin for the workgroups the reserved CUs burn (they exit at
+  // once there) and a tail of persistent "sweepers" that finish whatever the burnt ones left.  0, "persistent": about
+  // as many workgroups as the chip has slots, all looping (measured: the chain's wide launches then only get the
+  // reserved CUs until the update retires — C2 13.3 against 12.5 ms).
+  static const int form = [] {
+    const char* e = getenv("GPX_RESV_FORM");
+    return e ? atoi(e) : 1;
+  }();
+  unsigned sweep0 = 0;
+  auto resv_grid = [&](int64_t total) {
+    const int per_cu = BT == 128 ? 2 : (ks == 4 ? 1 : ks == 2 ? 2 : 4);
+    const int64_t slots = (int64_t)cu_count() * per_cu;
+    if (form == 0) {
+      sweep0 = 0;
+      return dim3((unsigned)(std::min<int64_t>(total, slots) + 64 * g_resv.k));
+    }
+    const int64_t sweepers = std::min<int64_t>(total, slots / 2);
+    const int64_t ones = total - sweepers + 256 * g_resv.k;  // one-tile workgroups incl. what the reserved CUs will burn
+    sweep0 = (unsigned)ones;
+    return dim3((unsigned)(ones + sweepers));
+  };
+#define GPX_NT_LAUNCH(TRI_, MODE_, SH_, MASK_)                                                                                  \
   do {                                                                                                                         \
-    if (ks == 4)                                                                                                               \
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, TRI_, MODE_, (BT == 64 ? 4 : 1)>), grid, block, spread, st, __VA_ARGS__);      \
+    if (rctr) {                                                                                                                \
+      const unsigned total_ = grid.x;                                                                                          \
+      const dim3 pg_ = resv_grid(total_);                                                                                      \
+      if (ks == 4)                                                                                                             \
+        hipLaunchKernelGGL((gemm_nt_resv_kernel<T, BT, TRI_, MODE_, (BT == 64 ? 4 : 1)>), pg_, block, 0, st, C, ldc, A, lda,   \
+                           B, ldb, (int)tm, (int)tn, SH_, MASK_, (int)k, total_, rctr, g_resv.k, sweep0);                              \
+      else if (ks == 2)                                                                                                        \
+        hipLaunchKernelGGL((gemm_nt_resv_kernel<T, BT, TRI_, MODE_, (BT == 64 ? 2 : 1)>), pg_, block, 0, st, C, ldc, A, lda,   \
+                           B, ldb, (int)tm, (int)tn, SH_, MASK_, (int)k, total_, rctr, g_resv.k, sweep0);                              \
+      else                                                                                                                     \
+        hipLaunchKernelGGL((gemm_nt_resv_kernel<T, BT, TRI_, MODE_, 1>), pg_, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm,   \
+                           (int)tn, SH_, MASK_, (int)k, total_, rctr, g_resv.k, sweep0);                                               \
+    } else if (ks == 4)                                                                                                        \
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, TRI_, MODE_, (BT == 64 ? 4 : 1)>), grid, block, spread, st, C, ldc, A, lda, B, \
+                         ldb, (int)tm, (int)tn, SH_, MASK_, bc, (int)k);                                                       \
     else if (ks == 2)                                                                                                          \
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, TRI_, MODE_, (BT == 64 ? 2 : 1)>), grid, block, spread, st, __VA_ARGS__);      \
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, TRI_, MODE_, (BT == 64 ? 2 : 1)>), grid, block, spread, st, C, ldc, A, lda, B, \
+                         ldb, (int)tm, (int)tn, SH_, MASK_, bc, (int)k);                                                       \
     else                                                                                                                       \
-      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, TRI_, MODE_, 1>), grid, block, spread, st, __VA_ARGS__);                       \
+      hipLaunchKernelGGL((gemm_nt_kernel<T, BT, TRI_, MODE_, 1>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm,    \
+                         (int)tn, SH_, MASK_, bc, (int)k);                                                                     \
   } while (0)
   if (lower == 1) {  // full lower triangle, triangular super-tile enumeration
     const int64_t ts = (tm + 7) / 8;
     dim3 grid((unsigned)(ts * (ts - 1) / 2 * 64 + ts * 36));  // tile_coords<TRI>: no masked slots
-    int band = 0;  // GPX_TRI_BAND = B > 1: banded super-tile order (tile_coords<true>; A/B experiment)
-    if (const char* e = getenv("GPX_TRI_BAND")) band = atoi(e) > 1 ? atoi(e) : 0;
     if (mode == 0)
-      GPX_NT_LAUNCH(true, 0, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, band, bc, (int)k);
+      GPX_NT_LAUNCH(true, 0, 8, 0);
     else
-      GPX_NT_LAUNCH(true, 1, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, 8, band, bc, (int)k);
+      GPX_NT_LAUNCH(true, 1, 8, 0);
   } else if (lower == 4) {  // C = A W^T, W lower triangular: paired tile columns (mode 1 only)
     int sh;
     dim3 grid((unsigned)rect_grid(tm, (tn + 1) / 2, sh));
-    if (ks == 4)
+    if (rctr) {
+      const unsigned total_ = grid.x;
+      const dim3 pg_ = resv_grid(total_);
+      if (ks == 4)
+        hipLaunchKernelGGL((gemm_nt_ltri_resv_kernel<T, BT, (BT == 64 ? 4 : 1)>), pg_, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, (int)k, total_, rctr, g_resv.k, sweep0);
+      else if (ks == 2)
+        hipLaunchKernelGGL((gemm_nt_ltri_resv_kernel<T, BT, (BT == 64 ? 2 : 1)>), pg_, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, (int)k, total_, rctr, g_resv.k, sweep0);
+      else
+        hipLaunchKernelGGL((gemm_nt_ltri_resv_kernel<T, BT, 1>), pg_, block, 0, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, (int)k, total_, rctr, g_resv.k, sweep0);
+    } else if (ks == 4)
       hipLaunchKernelGGL((gemm_nt_ltri_kernel<T, BT, (BT == 64 ? 4 : 1)>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, (int)k);
     else if (ks == 2)
       hipLaunchKernelGGL((gemm_nt_ltri_kernel<T, BT, (BT == 64 ? 2 : 1)>), grid, block, spread, st, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, (int)k);
@@ -1045,9 +1158,9 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
     dim3 grid((unsigned)rect_grid(tm, tn, sh));
     const int mask = lower == 2 ? 1 : lower == 3 ? 2 : 0;
     if (mode == 0)
-      GPX_NT_LAUNCH(false, 0, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
+      GPX_NT_LAUNCH(false, 0, sh, mask);
     else
-      GPX_NT_LAUNCH(false, 1, C, ldc, A, lda, B, ldb, (int)tm, (int)tn, sh, mask, bc, (int)k);
+      GPX_NT_LAUNCH(false, 1, sh, mask);
   }
 #undef GPX_NT_LAUNCH
 }
@@ -1057,6 +1170,15 @@ void launch_gemm_nt_t(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, in
 // A launcher that refuses its operands (the 128-byte row alignment trsm_rlt_kernel depends on)
 // launches nothing and raises this flag; every API entry point turns it into an error return.
 void set_latency_mode(int on) { g_latency_mode = on; }
+void reserve_ring(unsigned* ring, int cap) {
+  g_resv.ring = ring;
+  g_resv.cap = ring ? cap : 0;
+  g_resv.used = 0;
+  g_resv.k = 0;
+  g_resv.chain = 0;
+}
+void set_reserve_mode(int k) { g_resv.k = g_resv.ring ? k : 0; }
+void set_reserve_chain(int on) { g_resv.chain = g_resv.ring ? on : 0; }
 
 static thread_local int g_launch_error = 0;  // per host thread = per API call in flight (a handle is used by one thread at a time)
 int take_launch_error() {
@@ -1076,18 +1198,25 @@ template <typename T>
 void launch_potf2_128(T* A, int64_t lda, T* Winv, int64_t gidx0, int* info, hipStream_t st, unsigned* flag,
                       unsigned flag_val) {
   debug_delay(st);
-  // GPX_POTF2_EXCL=1 (experiment, with GPX_CU_RESERVE): pad the workgroup's LDS to the CU's whole 160 KB, so that
-  // it is only ever placed on an EMPTY CU (one the masked update stream leaves alone)
-  static const unsigned excl = [] {
-    const char* e = getenv("GPX_POTF2_EXCL");
-    if (!e || atoi(e) == 0) return 0u;
-    hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(potf2_128_kernel<T>)) != hipSuccess) return 0u;
-    const unsigned pad = 160u * 1024u - (unsigned)fa.sharedSizeBytes;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-    return pad;
-  }();
-  hipLaunchKernelGGL(potf2_128_kernel<T>, dim3(1), dim3(256), excl, st, A, lda, Winv, gidx0, info, flag, flag_val);
+  // Reserve mode, chain side: the POTF2 asks for so much LDS (130 KB in all) that no CU holding even ONE update workgroup
+  // (32 KB at least) can take it — it lands on a CU the self-reserving update leaves alone, where its fp64 vector work has
+  // the double-precision pipe to itself.  (Small-LDS kernels — the side stream's slabs — may still share that CU.)
+  unsigned pad = 0;
+  if (g_resv.chain) {
+    static const unsigned pad130 = [] {
+      hipFuncAttributes fa;
+      if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(potf2_128_kernel<T>)) != hipSuccess) return 0u;
+      const unsigned want = 130u * 1024u;
+      if (fa.sharedSizeBytes >= want) return 0u;
+      const unsigned p = want - (unsigned)fa.sharedSizeBytes;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)p) != hipSuccess)
+        return 0u;
+      return p;
+    }();
+    pad = pad130;
+  }
+  hipLaunchKernelGGL(potf2_128_kernel<T>, dim3(1), dim3(256), pad, st, A, lda, Winv, gidx0, info, flag, flag_val);
 }
 
 template <typename T>
@@ -1103,7 +1232,9 @@ void launch_trsm_rlt(T* X, int64_t ldx, int64_t rows, const T* L, int64_t ldl, c
   }
   // few slabs (the diagonal chain, the alpha solves): every product is one latency-bound walk -> KS64 lines
   // per barrier; many slabs: the plain engine, whose occupancy hides the latency
-  if (g_latency_mode && rows / 64 <= cu_count())
+  // (reserve mode, chain side: a narrow slab launch takes the KS64 form too — 128 KB of LDS per workgroup, which only an
+  // empty CU holds, i.e. one the self-reserving update leaves alone)
+  if ((g_latency_mode && rows / 64 <= cu_count()) || (g_resv.chain > 1 && rows / 64 <= 16))
     hipLaunchKernelGGL((trsm_rlt_kernel<T, Num<T>::KS64>), dim3((unsigned)(rows / 64)), dim3(256), 0, st, X, ldx, L, ldl,
                        Winv, 0, nb / 64, P, ldp, 0, (T*)nullptr, (int64_t)0, 0);
   else
@@ -1163,27 +1294,6 @@ void launch_gemm_nt_fixed(int tile, T* C, int64_t ldc, const T* A, int64_t lda, 
                           int64_t m, int64_t n, int64_t k, int lower, int mode, hipStream_t st) {
   debug_delay(st);
   if (m <= 0 || n <= 0) return;
-  static const bool tall = [] {
-    const char* e = getenv("GPX_SYRK_TALL");
-    return e && atoi(e) != 0;
-  }();
-  if (tall && lower == 1 && mode == 0 && tile == 128 && m == n && m % 256 == 0 && m / 256 <= 8 * STAIR_MAX) {
-    const BcMask bc2{2, 1, 1};
-    StairMap map;
-    const unsigned total = build_stair_map(bc2, m / 256, n / 128, map);
-    hipLaunchKernelGGL((gemm_nt_tall_kernel<T, 0>), dim3(total), dim3(512), 0, st, C, ldc, A, lda, B, ldb,
-                       (int)(m / 256), (int)(n / 128), bc2, (int)k, map);
-    return;
-  }
-  if (lower == 1 && mode == 0 && tile == 128 && m == n && k % (2 * Num<T>::BK) == 0) {
-    const char* e = getenv("GPX_SYRK_W8");  // read per call: an A/B switch
-    if (e && atoi(e) != 0) {
-      const int64_t tm = m / 128, ts = (tm + 7) / 8;
-      hipLaunchKernelGGL((gemm_nt_w8_kernel<T, 0>), dim3((unsigned)(ts * (ts - 1) / 2 * 64 + ts * 36)), dim3(512), 0, st, C,
-                         ldc, A, lda, B, ldb, (int)tm, (int)tm, (int)k);
-      return;
-    }
-  }
   const BcMask bc{0, 1, 0};
   if (tile == 128)
     launch_gemm_nt_t<T, 128>(C, ldc, A, lda, B, ldb, m, n, k, lower, mode, bc, st);
@@ -1276,17 +1386,6 @@ int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, i
     for (int64_t b = 0; b < grid; ++b) {
       int ti, tj;
       if (!tile_coords<true>(xcd_chunk_id(b, grid), (int)tm, (int)tm, 8, 0, BcMask{0, 1, 0}, ti, tj)) continue;
-      if (n >= cap) return -1;
-      out[2 * n] = ti;
-      out[2 * n + 1] = tj;
-      ++n;
-    }
-  } else if (kind == 3) {  // lower triangle in the banded super-tile order, band height tn
-    const int64_t ts = (tm + 7) / 8;
-    const int64_t grid = ts * (ts - 1) / 2 * 64 + ts * 36;
-    for (int64_t b = 0; b < grid; ++b) {
-      int ti, tj;
-      if (!tile_coords<true>(xcd_chunk_id(b, grid), (int)tm, (int)tm, 8, (int)tn, BcMask{0, 1, 0}, ti, tj)) continue;
       if (n >= cap) return -1;
       out[2 * n] = ti;
       out[2 * n + 1] = tj;

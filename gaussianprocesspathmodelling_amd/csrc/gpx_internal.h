@@ -73,6 +73,16 @@ void launch_inv_extend(T* U, int64_t ldu, const T* L, int64_t ldl, const T* Winv
 // barrier — 64 or 128 KB of LDS per workgroup instead of 32 — which shortens every latency-bound K walk
 // when the GPU is otherwise idle and must NOT be used beside a large trailing update (see gpx_blas.hip).
 void set_latency_mode(int on);
+// Reserve mode of the calling host thread (round 4; gemm_nt_resv_kernel in gpx_blas.hip).
+// reserve_ring(ring, cap): start of a factorisation — `ring` = [cap][8] device counters the caller has zeroed (null: off).
+// set_reserve_mode(k): k > 0 — the products launch_gemm_nt enqueues from now on go out as persistent grids whose
+//   workgroups leave k CUs per XCD alone (they exit at once there) and take their tiles from the next 8 counters of
+//   the ring; launches beyond cap, and k = 0, are the plain kernels.
+// set_reserve_chain(1): the chain's narrow slab launches (launch_trsm_rlt, <= 16 slabs) ask for a whole CU's LDS, so
+//   that they land on the CUs the update leaves alone.
+void reserve_ring(unsigned* ring, int cap);
+void set_reserve_mode(int k);
+void set_reserve_chain(int on);
 // 1 if a launcher CALLED BY THIS HOST THREAD since the last call refused misaligned operands (and launched nothing);
 // clears the flag.  Thread-local: an API call enqueues and checks on one thread, so a handle only ever sees its own
 // launches' errors (distinct handles on distinct threads: include/gpx.h)

@@ -282,31 +282,6 @@ __host__ __device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, i
     if (lin < full) {
       int i, j;
       tri_coords(st, i, j);  // strictly lower: super-row i + 1, super-column j
-      if (mask_lower > 1) {
-        // BANDED order (experiment, round 3; mask_lower = band height B, unused otherwise by the TRI map):
-        // super-rows in bands of B, inside a band column by column — a B operand block (super-column j)
-        // is then used by B super-rows in a row instead of once per super-row, i.e. the panel prefix is
-        // re-read from beyond the L2 once per band.  Band b = rows [B b, B b + B) of the strictly lower
-        // triangle holds exactly the slots [T(B b), T(B b + B)) of the plain order, so only the order
-        // inside a band changes.
-        const int B = mask_lower, R = S - 1;
-        const int i0 = (i / B) * B;
-        const int nrows = (i0 + B <= R ? B : R - i0);
-        const int64_t off = st - (int64_t)i0 * (i0 + 1) / 2;         // slot inside the band
-        const int64_t rect = (int64_t)(i0 + 1) * nrows;               // columns 0..i0 exist in every row of the band
-        if (off < rect) {
-          j = (int)(off / nrows);
-          i = i0 + (int)(off - (int64_t)j * nrows);
-        } else {                                                     // ragged tail: row i0 + r has r more columns
-          int e = (int)(off - rect), r = 1;
-          while (e >= r) {
-            e -= r;
-            ++r;
-          }
-          i = i0 + r;
-          j = i0 + 1 + e;
-        }
-      }
       ti = (i + 1) * 8 + (inner >> 3);
       tj = j * 8 + (inner & 7);
     } else {

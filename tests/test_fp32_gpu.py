@@ -36,17 +36,3 @@ def test_fp32_rejects_sharding():
     from gaussianprocesspathmodelling_amd import GpxError
     with pytest.raises(GpxError):
         GP("rbf", 0.3, dtype="float32", world=2, rank=0, comm="host")
-
-
-def test_fp32_eight_wave_variant_is_bit_identical(monkeypatch):
-    """GPX_SYRK_W8=1 (round 3): the trailing update as 128 x 128 tiles on EIGHT waves with two k-steps per
-    barrier (gemm_nt_w8_kernel, the "BK = 64" fp32 experiment).  Same products in the same order per
-    element, other wave geometry: the fp32 fit must not change by a bit."""
-    X, y, Xs = synthetic_problem(12288, 3, 200, seed=12)
-    with GP("rbf", (0.3, 0.2, 0.25), 1.5, 1e-1, jitter=0.0, dtype="float32") as gp:
-        m0, v0 = gp.fit(X, y).predict(Xs)
-    monkeypatch.setenv("GPX_SYRK_W8", "1")
-    with GP("rbf", (0.3, 0.2, 0.25), 1.5, 1e-1, jitter=0.0, dtype="float32") as gp:
-        m1, v1 = gp.fit(X, y).predict(Xs)
-        assert gp.info_ == 0
-    assert np.array_equal(m0, m1) and np.array_equal(v0, v1)

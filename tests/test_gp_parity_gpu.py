@@ -347,15 +347,16 @@ def test_hyperparameter_optimisation_climbs_the_marginal_likelihood():
 
 
 @pytest.mark.parametrize("env", [{"GPX_FUSED_STRIP": "1"}, {"GPX_DIAG_STEP": "64"},
-                                 {"GPX_FUSED_STRIP": "1", "GPX_DIAG_STEP": "64"}, {"GPX_SYRK_W8": "1"},
+                                 {"GPX_FUSED_STRIP": "1", "GPX_DIAG_STEP": "64"}, {"GPX_CU_SELF_RESERVE": "1"}, {"GPX_CU_SELF_RESERVE": "4"},
                                  {"GPX_CHAIN_FLAG": "0"},
                                  {"GPX_SPLIT_STRIP": "0"}, {"GPX_SPLIT_STRIP": "0", "GPX_CHAIN_FLAG": "0"},
                                  {"GPX_REST_SPLIT": "0"}, {"GPX_REST_SPLIT": "4"}, {"GPX_SOLVE_TOP": "0"}])
 def test_schedule_variants_give_the_same_factorisation(monkeypatch, env):
     """Round-3 schedule switches of the blocked Cholesky: the fused trailing update (strip + rest in ONE
     launch, device-counter hand-over to the look-ahead stream: gemm_nt_fused_kernel / wait_counter_kernel)
-    the 64-wide diagonal stepping (the default steps 128 columns per launch: potf2_128_kernel), and the
-    experimental eight-wave / two-k-steps-per-barrier trailing update (gemm_nt_w8_kernel, GPX_SYRK_W8=1), and the
+    the 64-wide diagonal stepping (the default steps 128 columns per launch: potf2_128_kernel), the self-reserving
+    trailing update of the chain-bound panels (round 4: persistent workgroups that leave k CUs per XCD to the diagonal
+    chain and take their tiles from device counters: gemm_nt_resv_kernel, GPX_CU_SELF_RESERVE=k), and the
     hipEvent hand-over of the diagonal chain (GPX_CHAIN_FLAG=0; the default is a device flag: what `rocprofv3 --pmc` needs).
     N = 12288 with 1024-panels: 11 trailing updates, the first 8 of them large enough to fuse.  Against
     the oracle at 1e-6 and against the default schedule: the fused launch does the same arithmetic per

@@ -97,13 +97,3 @@ def test_fused_strip_plus_rest_map_is_a_bijection(gpx, tm, ts):
     is_strip = [j < ts for _, j in got]
     nstrip = sum(is_strip)
     assert all(is_strip[:nstrip]) and not any(is_strip[nstrip:])
-
-
-@pytest.mark.parametrize("tm,band", [(504, 4), (64, 4), (65, 4), (9, 4), (100, 2), (256, 8), (33, 3), (17, 16)])
-def test_banded_triangle_map_is_a_bijection(gpx, tm, band):
-    """GPX_TRI_BAND (experiment): the same lower triangle with the super-tiles of `band` super-rows enumerated
-    column by column — every tile exactly once."""
-    pairs = tile_map(gpx, 3, tm, band)
-    want = {(i, j) for i in range(tm) for j in range(i + 1)}
-    got = [tuple(p) for p in pairs.tolist()]
-    assert len(got) == len(set(got)) == len(want) and set(got) == want
