@@ -100,6 +100,7 @@ struct gpx_handle {
   DevBuf AT;
   DevBuf ZT, gpart;  // gpx_lml_grad: L^-T (Npad x ld) and the per-tile partial sums
   // GPX_MIXED: fp64 side of the mixed-precision mode (the fp32 engine uses the buffers above)
+  DevBuf RTloc, P32out;  // GPX_MIXED on a distributed shard: local columns of the refinement's right-hand sides; fp32 predict outputs
   DevBuf X64, Y64, Xs64, A64, Aprev, R64, X32, Y32, RT32, Q64, Qs64, Q32, M64, rn, Zfew;
   int refine = 0;    // GPX_MIXED: 0 = adaptive, > 0 = fixed iteration count
   DevBuf Tsol;       // predict: compact solved blocks of V^T (2 x batch x (nb + skew))
@@ -1441,34 +1442,39 @@ int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d,
               const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter, int32_t mem_kind,
               int64_t* info) {
   if (k > MIXED_KMAX) return fail(h, GPX_E_ARG, "gpx_fit: the mixed-precision mode takes at most 8 target columns");
-  const int64_t Npad = round_up(N, TILE);
   int rc;
   if ((rc = ensure(h, h->X64, (size_t)N * d * 8))) return rc;
   if ((rc = ensure(h, h->Y64, (size_t)N * k * 8))) return rc;
-  if ((rc = ensure(h, h->Xs64, (size_t)Npad * d * 8))) return rc;
   if ((rc = ensure(h, h->X32, (size_t)N * d * 4))) return rc;
   if ((rc = ensure(h, h->Y32, (size_t)N * k * 4))) return rc;
-  if ((rc = ensure(h, h->A64, (size_t)MIXED_KMAX * Npad * 8))) return rc;
-  if ((rc = ensure(h, h->R64, (size_t)MIXED_KMAX * Npad * 8))) return rc;
-  if ((rc = ensure(h, h->Aprev, (size_t)MIXED_KMAX * Npad * 8))) return rc;
-  if ((rc = ensure(h, h->rn, 64))) return rc;
   if ((rc = ensure(h, h->ls, 32 * 8))) return rc;
   hipStream_t st = h->st;
   if ((rc = copy_in(h, h->X64.p, X, (size_t)N * d * 8, mem_kind))) return rc;
   if ((rc = copy_in(h, h->Y64.p, y, (size_t)N * k * 8, mem_kind))) return rc;
   launch_f64_to_f32((const double*)h->X64.p, (float*)h->X32.p, N * d, st);
   launch_f64_to_f32((const double*)h->Y64.p, (float*)h->Y32.p, N * k, st);
-  // the whole fp32 fit (kernel build, blocked Cholesky, z = L^-1 y) on the device copies
-  if ((rc = fit_impl<float>(h, h->X32.p, h->Y32.p, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, GPX_MEM_DEVICE,
-                            info)))
-    return rc;
+  // the whole fp32 fit (kernel build, blocked Cholesky, z = L^-1 y) on the device copies — on a shard (round 4) the
+  // sharded fp32 fit: every rank holds the same fp64 inputs and runs the same refinement (replicated fp64 work)
+  if (h->comm)
+    rc = shard_fit<float>(h, h->X32.p, h->Y32.p, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, GPX_MEM_DEVICE, info);
+  else
+    rc = fit_impl<float>(h, h->X32.p, h->Y32.p, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, GPX_MEM_DEVICE, info);
+  if (rc) return rc;
   gpx_timings& tm = h->tm;
   tm.refine = tm.refine_resid0 = tm.refine_resid = tm.refine_iters = 0;
   if (*info != 0) return GPX_OK;
+  const int64_t Npad = h->Npad;  // the fp32 side's padding (a shard pads to its block height): the fp64 side follows it
+  if ((rc = ensure(h, h->Xs64, (size_t)Npad * d * 8))) return rc;
+  if ((rc = ensure(h, h->A64, (size_t)MIXED_KMAX * Npad * 8))) return rc;
+  if ((rc = ensure(h, h->R64, (size_t)MIXED_KMAX * Npad * 8))) return rc;
+  if ((rc = ensure(h, h->Aprev, (size_t)MIXED_KMAX * Npad * 8))) return rc;
+  if ((rc = ensure(h, h->rn, 64))) return rc;
+  const bool dist = h->comm && !h->repl;  // factor only held distributed: the refinement's solves are collective
+  if (dist && (rc = ensure(h, h->RTloc, (size_t)RHS_ROWS * h->ldy * 4))) return rc;
   const int64_t ld32 = h->ld;
   if ((rc = ensure(h, h->RT32, (size_t)RHS_ROWS * ld32 * 4))) return rc;
-  const bool few = few_solver_applies(h);
-  if ((rc = ensure_alpha<float>(h))) return rc;
+  const bool few = !dist && few_solver_applies(h);
+  if (!dist && (rc = ensure_alpha<float>(h))) return rc;  // (distributed: the fit left alpha^T replicated in YT)
   double* A64 = (double*)h->A64.p;
   double* R64 = (double*)h->R64.p;
   double* rn = (double*)h->rn.p;
@@ -1521,7 +1527,15 @@ int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d,
     // delta = (L L^T)^-1 r in fp32; alpha += delta in fp64 (adaptive: the iterate before the correction is kept)
     if (adaptive) HIPCHK(h, hipMemcpyAsync(h->Aprev.p, A64, (size_t)MIXED_KMAX * Npad * 8, hipMemcpyDeviceToDevice, st));
     launch_rows_f64_to_f32(R64, Npad, (float*)h->RT32.p, ld32, k, RHS_ROWS, N, Npad, st);
-    if (few) {
+    if (dist) {  // own column blocks of the residual rows -> the distributed solve -> delta replicated in RT32 again
+      const int nb = h->nb_shard;
+      const Shard sh{h->comm->world, h->comm->rank, nb, Npad / nb};
+      float* Rl = (float*)h->RTloc.p;
+      for (int64_t lb = 0; lb < sh.nlb(sh.r); ++lb)
+        HIPCHK(h, hipMemcpy2DAsync(Rl + lb * nb, (size_t)h->ldy * 4, (const float*)h->RT32.p + (lb * sh.P + sh.r) * nb,
+                                   (size_t)ld32 * 4, (size_t)nb * 4, RHS_ROWS, hipMemcpyDeviceToDevice, st));
+      if ((rc = shard_solve_dist<float>(h, sh, Rl, (float*)h->RT32.p))) return rc;
+    } else if (few) {
       if ((rc = solve_few<float>(h, (float*)h->RT32.p, k, L32, ld32, Npad, (const float*)h->Wblk.p, h->nbw))) return rc;
     } else {
       if ((rc = solve_fwd_enqueue<float>(h, (float*)h->RT32.p, RHS_ROWS, L32, ld32, Npad, h->nb_solve,
@@ -1560,10 +1574,30 @@ int mixed_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* va
   double* mout = MT64 + MIXED_KMAX * Mpad;     // (M x k)
   double* vout = mout + (size_t)M * k;         // (M)
   hipStream_t st = h->st;
+  double shard_ms[6] = {0, 0, 0, 0, 0, 0};  // a sharded variance predict is a call of its own: its clocks are added below
+  if (var && h->comm) {
+    // Variance through the sharded fp32 factor (round 4): the whole sharded predict — collective, every rank — into
+    // device scratch, before this call's own phases (it synchronises and folds its own clocks).  Its fp32 mean is not
+    // used: the mean comes from the refined fp64 alpha below, replicated work on every rank.
+    if ((rc = ensure(h, h->P32out, (size_t)M * (k + 1) * 4))) return rc;
+    if ((rc = copy_in(h, h->Q64.p, Xq, (size_t)M * d * 8, mem_kind))) return rc;
+    launch_f64_to_f32((const double*)h->Q64.p, (float*)h->Q32.p, M * d, st);
+    float* m32 = (float*)h->P32out.p;
+    float* v32 = m32 + (size_t)M * k;
+    const bool discard = h->discard_out;
+    h->discard_out = false;  // the scratch outputs are wanted on every rank
+    rc = shard_predict<float>(h, h->Q32.p, M, m32, v32, GPX_MEM_DEVICE);
+    h->discard_out = discard;
+    if (rc) return rc;
+    const double keep[6] = {tm.kstar, tm.trsm, tm.var, tm.mean, tm.predict_total, tm.comm};
+    for (int i = 0; i < 6; ++i) shard_ms[i] = keep[i];
+    tm.kstar = tm.mean = tm.trsm = tm.var = tm.d2h = tm.predict_total = 0;
+    launch_f32_to_f64(v32, vout, M, st);
+  }
   {
     PhaseScope total(h, &tm.predict_total);
     if ((rc = copy_in(h, h->Q64.p, Xq, (size_t)M * d * 8, mem_kind))) return rc;
-    if (var) {  // variance through the fp32 factor (its own K*, V^T = K* L^-T, row sums)
+    if (var && !h->comm) {  // variance through the fp32 factor (its own K*, V^T = K* L^-T, row sums)
       launch_f64_to_f32((const double*)h->Q64.p, (float*)h->Q32.p, M * d, st);
       if ((rc = predict_core<float>(h, h->Q32.p, M, true, GPX_MEM_DEVICE))) return rc;
       launch_f32_to_f64((const float*)h->var.p, vout, M, st);
@@ -1577,13 +1611,19 @@ int mixed_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* va
       launch_unpack_rhs<double>(MT64, Mpad, M, k, 1.0, mout, st);
     }
     PhaseScope ps(h, &tm.d2h);
-    if ((rc = copy_out(h, mean, mout, (size_t)M * k * 8, mem_kind))) return rc;
-    if (var && (rc = copy_out(h, var, vout, (size_t)M * 8, mem_kind))) return rc;
+    if (!h->discard_out) {  // a group's ranks > 0 hold the same result; rank 0 delivers it
+      if ((rc = copy_out(h, mean, mout, (size_t)M * k * 8, mem_kind))) return rc;
+      if (var && (rc = copy_out(h, var, vout, (size_t)M * 8, mem_kind))) return rc;
+    }
   }
   HIPCHK(h, hipStreamSynchronize(st));
   HIPCHK(h, hipGetLastError());
   LAUNCHCHK(h);
   collect_phases(h);
+  tm.kstar += shard_ms[0];
+  tm.trsm += shard_ms[1];
+  tm.var += shard_ms[2];
+  tm.predict_total += shard_ms[4];
   (void)N;
   return GPX_OK;
 }
@@ -1635,8 +1675,6 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) try {
     return fail(nullptr, GPX_E_ARG, "gpx_create: unknown kernel id");
   if (cfg->dtype != GPX_F64 && cfg->dtype != GPX_F32 && cfg->dtype != GPX_MIXED)
     return fail(nullptr, GPX_E_ARG, "gpx_create: unknown dtype id");
-  if (cfg->dtype != GPX_F64 && cfg->world > 1)
-    return fail(nullptr, GPX_E_UNSUPPORTED, "gpx_create: the row-block shard is fp64 only");
   if (cfg->refine < 0 || cfg->refine > 50) return fail(nullptr, GPX_E_ARG, "gpx_create: need 0 <= refine <= 50");
   if (cfg->world < 1 || cfg->world > 64 || cfg->rank < 0 || cfg->rank >= cfg->world)
     return fail(nullptr, GPX_E_ARG, "gpx_create: need 1 <= world <= 64 and 0 <= rank < world");
@@ -1709,7 +1747,7 @@ void gpx_destroy(gpx_handle* h) {
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->MTpart, &h->var, &h->meanout, &h->G, &h->Pglob,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
                     &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->ZTloc, &h->ZTpack, &h->gpart, &h->Wblk, &h->Ublk, &h->Tsol, &h->X64, &h->Y64, &h->Xs64,
-                    &h->A64, &h->Aprev, &h->R64, &h->resv_ring, &h->X32, &h->Y32, &h->RT32, &h->Q64, &h->Qs64, &h->Q32, &h->M64, &h->rn, &h->Zfew})
+                    &h->A64, &h->Aprev, &h->R64, &h->resv_ring, &h->RTloc, &h->P32out, &h->X32, &h->Y32, &h->RT32, &h->Q64, &h->Qs64, &h->Q32, &h->M64, &h->rn, &h->Zfew})
     release(*b);
   destroy_comm(h);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
@@ -1741,8 +1779,11 @@ int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, i
   h->err.clear();
   h->phases.clear();  // an earlier call that failed mid-way must not leak its event pairs
   h->ev_used = 0;
-  if (h->cfg.world > 1 || h->comm)  // a 1-rank communicator also takes the sharded schedule
-    return shard_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
+  if (h->cfg.world > 1 || h->comm) {  // a 1-rank communicator also takes the sharded schedule
+    if (h->cfg.dtype == GPX_MIXED) return mixed_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
+    if (h->cfg.dtype == GPX_F32) return shard_fit<float>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
+    return shard_fit<double>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
+  }
 
   if (h->cfg.dtype == GPX_MIXED)
     return mixed_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
@@ -1796,7 +1837,11 @@ int gpx_predict(gpx_handle* h, const void* Xq, int64_t M, void* mean, void* var,
   h->err.clear();
   h->phases.clear();
   h->ev_used = 0;
-  if (h->cfg.world > 1 || h->comm) return shard_predict(h, Xq, M, mean, var, mem_kind);
+  if (h->cfg.world > 1 || h->comm) {
+    if (h->cfg.dtype == GPX_MIXED) return mixed_predict(h, Xq, M, mean, var, mem_kind);
+    if (h->cfg.dtype == GPX_F32) return shard_predict<float>(h, Xq, M, mean, var, mem_kind);
+    return shard_predict<double>(h, Xq, M, mean, var, mem_kind);
+  }
   if (h->cfg.dtype == GPX_MIXED) return mixed_predict(h, Xq, M, mean, var, mem_kind);
   if (h->cfg.dtype == GPX_F32) return predict_impl<float>(h, Xq, M, mean, var, mem_kind);
   return predict_impl<double>(h, Xq, M, mean, var, mem_kind);

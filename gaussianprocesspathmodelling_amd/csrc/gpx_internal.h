@@ -217,26 +217,33 @@ void launch_few_product(bool cols, bool assign, T* out, int64_t ldo, const T* M,
 void launch_path_distance(const double* paths, int64_t P, const double* cents, int C, int L, double* D,
                           int64_t ldd, hipStream_t st);
 
-// ---- row-block-cyclic shard helpers (gpx_misc.hip, fp64) ----------------------------------
+// ---- row-block-cyclic shard helpers (gpx_misc.hip; T = double | float) ------------------------
 // A[i][i] = i < nvalid ? A[i][i] + add : 1   for i < n (diagonal of one local row block)
-void launch_fix_diag(double* A, int64_t lda, int n, int nvalid, double add, hipStream_t st);
+template <typename T>
+void launch_fix_diag(T* A, int64_t lda, int n, int nvalid, double add, hipStream_t st);
 // Gathered panel G [P][maxcnt][ldp] (rank-major, each rank's trailing rows in local order)
 // -> Pglob [(nblk-p-1)*nb][ldp] in global row order.
-void launch_unpermute_panel(const double* G, double* Pglob, int64_t ldp, int nb, int P, int p,
-                            int nblk, int64_t maxcnt, hipStream_t st);
+template <typename T>
+void launch_unpermute_panel(const T* G, T* Pglob, int64_t ldp, int nb, int P, int p, int nblk, int64_t maxcnt,
+                            hipStream_t st);
 // YTloc[r][lb*nb + i] = y[(g*nb+i)*k + r] for the blocks g = rank + lb*P owned by `rank`.
-void launch_pack_rhs_local(const double* y, int64_t n, int k, double* YTloc, int64_t ldy, int nb,
-                           int nlb, int P, int rank, int R, hipStream_t st);
+template <typename T>
+void launch_pack_rhs_local(const T* y, int64_t n, int k, T* YTloc, int64_t ldy, int nb, int nlb, int P, int rank, int R,
+                           hipStream_t st);
 // Full[r][g*nb + i] = Loc[r][lb*nb + i] (own blocks), rest untouched.
-void launch_scatter_local(const double* Loc, int64_t ldl, double* Full, int64_t ldf, int nb, int nlb,
-                          int P, int rank, int R, hipStream_t st);
+template <typename T>
+void launch_scatter_local(const T* Loc, int64_t ldl, T* Full, int64_t ldf, int nb, int nlb, int P, int rank, int R,
+                          hipStream_t st);
 // dst (rows x cols, ldd) += sign * src (rows x cols, lds)
-void launch_add_block(double* dst, int64_t ldd, const double* src, int64_t lds, int rows, int cols,
-                      double sign, hipStream_t st);
-void launch_add_scalar(double* p, int64_t count, double v, hipStream_t st);
+template <typename T>
+void launch_add_block(T* dst, int64_t ldd, const T* src, int64_t lds, int rows, int cols, double sign, hipStream_t st);
+template <typename T>
+void launch_add_scalar(T* p, int64_t count, double v, hipStream_t st);
 // dst[i] = op over q < P of src[q*count + i] in rank order (op 0 sum, 1 min); dst may not alias src
-void launch_reduce_ranks(const double* src, double* dst, int P, int64_t count, int op, hipStream_t st);
+template <typename T>
+void launch_reduce_ranks(const T* src, T* dst, int P, int64_t count, int op, hipStream_t st);
 // out[0] += 2 * sum_i log(A[i][i]), i < n (one diagonal block)
-void launch_logdet_acc(const double* A, int64_t lda, int n, double* out, hipStream_t st);
+template <typename T>
+void launch_logdet_acc(const T* A, int64_t lda, int n, double* out, hipStream_t st);
 
 }  // namespace gpx

@@ -56,8 +56,9 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const T* __restrict__ As, i
                                                     int tiles_n, T sf2, T diag_add, T* __restrict__ K,
                                                     int64_t ld) {
   const int d = (D > 0) ? D : d_rt;
-  __shared__ T xa[KT * MAXD];
-  __shared__ T xb[KT * MAXD];
+  // LDS sized by the instantiation (d = 3: 2 x 1.5 KB, not 2 x 16 KB): the occupancy is then the waves', not the LDS's
+  __shared__ T xa[KT * (D > 0 ? D : MAXD)];
+  __shared__ T xb[KT * (D > 0 ? D : MAXD)];
   int ti, tj;
   if (SYM) {
     tri_coords((int64_t)blockIdx.x, ti, tj);
@@ -116,9 +117,11 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const T* __restrict__ As, i
     }
     typedef T pair_t __attribute__((ext_vector_type(2)));
     pair_t out = {v0, v1};
-    // (round 3: non-temporal stores here measured the same, 3.75-4.1 ms against 3.7-4.1 ms at N = 65536 on
-    //  one card, alternating processes: tools/kbuild_ab.py; plain stores kept)
-    *reinterpret_cast<pair_t*>(K + row * ld + col0) = out;
+    // Non-temporal 16-byte stores: nothing re-reads a tile before the whole matrix (17 GB) has gone by.  Round 4,
+    // tools/kbuild_variants.hip, twelve variants side by side in one process at N = 65536 (profiles/r04_kbuild_variants.txt):
+    // this kernel 3.36 ms = 5.1 TB/s against 3.52 with plain stores and 3.58 with the 2 x 16 KB static LDS of rounds 1-3;
+    // unrolling (1 / 2 / 4 / 8 rows), persistent tile walks, row strips and an occupancy hint all land within 3.4-3.9 ms.
+    __builtin_nontemporal_store(out, reinterpret_cast<pair_t*>(K + row * ld + col0));
   }
 }
 

@@ -144,49 +144,50 @@ __global__ __launch_bounds__(256) void copy_kernel(const double2* __restrict__ s
                                 reinterpret_cast<v2*>(dst) + i);
 }
 
-__global__ __launch_bounds__(256) void fix_diag_kernel(double* A, int64_t lda, int n, int nvalid,
-                                                      double add) {
+template <typename T>
+__global__ __launch_bounds__(256) void fix_diag_kernel(T* A, int64_t lda, int n, int nvalid, double add) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  double* p = A + (int64_t)i * lda + i;
-  *p = (i < nvalid) ? *p + add : 1.0;
+  T* p = A + (int64_t)i * lda + i;
+  *p = (i < nvalid) ? *p + (T)add : (T)1;
 }
 
-__global__ __launch_bounds__(256) void unpermute_panel_kernel(const double* __restrict__ G,
-                                                             double* __restrict__ Pglob, int64_t ldp,
+template <typename T>
+__global__ __launch_bounds__(256) void unpermute_panel_kernel(const T* __restrict__ G, T* __restrict__ Pglob, int64_t ldp,
                                                              int nb, int P, int p, int64_t maxcnt) {
   // blockIdx.y = trailing block b (global block g = p+1+b), blockIdx.x strides rows of the block
+  typedef float v4 __attribute__((ext_vector_type(4)));  // 16-byte pieces whatever the element type
+  constexpr int E = 16 / (int)sizeof(T);
   const int g = p + 1 + blockIdx.y;
   const int rr = g % P;
   const int lb0 = (p >= rr) ? (p - rr) / P + 1 : 0;
   const int64_t src_row0 = (int64_t)rr * maxcnt + (int64_t)(g / P - lb0) * nb;
   const int64_t dst_row0 = (int64_t)blockIdx.y * nb;
-  const int c2 = nb / 2;  // double2 per row
+  const int c2 = nb / E;  // pieces per row
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)nb * c2;
        e += (int64_t)gridDim.x * 256) {
     const int64_t row = e / c2;
-    const int col = (int)(e - row * c2) * 2;
-    *reinterpret_cast<double2*>(Pglob + (dst_row0 + row) * ldp + col) =
-        *reinterpret_cast<const double2*>(G + (src_row0 + row) * ldp + col);
+    const int col = (int)(e - row * c2) * E;
+    *reinterpret_cast<v4*>(Pglob + (dst_row0 + row) * ldp + col) =
+        *reinterpret_cast<const v4*>(G + (src_row0 + row) * ldp + col);
   }
 }
 
-__global__ __launch_bounds__(256) void pack_rhs_local_kernel(const double* __restrict__ y, int64_t n,
-                                                            int k, double* __restrict__ YTloc,
-                                                            int64_t ldy, int nb, int nlb, int P,
-                                                            int rank) {
+template <typename T>
+__global__ __launch_bounds__(256) void pack_rhs_local_kernel(const T* __restrict__ y, int64_t n, int k, T* __restrict__ YTloc,
+                                                            int64_t ldy, int nb, int nlb, int P, int rank) {
   const int r = blockIdx.y;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < (int64_t)nlb * nb;
        j += (int64_t)gridDim.x * 256) {
     const int64_t lb = j / nb;
     const int64_t gi = (lb * P + rank) * nb + (j - lb * nb);
-    YTloc[(int64_t)r * ldy + j] = (r < k && gi < n) ? y[gi * k + r] : 0.0;
+    YTloc[(int64_t)r * ldy + j] = (r < k && gi < n) ? y[gi * k + r] : (T)0;
   }
 }
 
-__global__ __launch_bounds__(256) void scatter_local_kernel(const double* __restrict__ Loc, int64_t ldl,
-                                                           double* __restrict__ Full, int64_t ldf,
-                                                           int nb, int nlb, int P, int rank) {
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_local_kernel(const T* __restrict__ Loc, int64_t ldl, T* __restrict__ Full,
+                                                           int64_t ldf, int nb, int nlb, int P, int rank) {
   const int r = blockIdx.y;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < (int64_t)nlb * nb;
        j += (int64_t)gridDim.x * 256) {
@@ -196,95 +197,104 @@ __global__ __launch_bounds__(256) void scatter_local_kernel(const double* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void add_block_kernel(double* __restrict__ dst, int64_t ldd,
-                                                       const double* __restrict__ src, int64_t lds,
-                                                       int rows, int cols, double sign) {
+template <typename T>
+__global__ __launch_bounds__(256) void add_block_kernel(T* __restrict__ dst, int64_t ldd, const T* __restrict__ src,
+                                                       int64_t lds, int rows, int cols, double sign) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)rows * cols;
        e += (int64_t)gridDim.x * 256) {
     const int64_t r = e / cols;
     const int64_t c = e - r * cols;
-    dst[r * ldd + c] += sign * src[r * lds + c];
+    dst[r * ldd + c] += (T)sign * src[r * lds + c];
   }
 }
 
-__global__ __launch_bounds__(256) void add_scalar_kernel(double* p, int64_t count, double v) {
+template <typename T>
+__global__ __launch_bounds__(256) void add_scalar_kernel(T* p, int64_t count, double v) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
-    p[i] += v;
+    p[i] += (T)v;
 }
 
 // dst[i] = op over q < P of src[q * count + i], in rank order (in-process transport: every rank
 // that reduces gets bit-identical results); op 0 = sum, 1 = min
-__global__ __launch_bounds__(256) void reduce_ranks_kernel(const double* __restrict__ src,
-                                                          double* __restrict__ dst, int P, int64_t count,
-                                                          int op) {
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_ranks_kernel(const T* __restrict__ src, T* __restrict__ dst, int P,
+                                                          int64_t count, int op) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
-    double v = src[i];
+    T v = src[i];
     for (int q = 1; q < P; ++q) {
-      const double w = src[(int64_t)q * count + i];
-      v = op == 1 ? fmin(v, w) : v + w;
+      const T w = src[(int64_t)q * count + i];
+      v = op == 1 ? (w < v ? w : v) : v + w;
     }
     dst[i] = v;
   }
 }
 
-__global__ __launch_bounds__(256) void logdet_acc_kernel(const double* __restrict__ A, int64_t lda,
-                                                        int n, double* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(256) void logdet_acc_kernel(const T* __restrict__ A, int64_t lda, int n,
+                                                        double* __restrict__ out) {
   __shared__ double red[4];
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s += log(A[i * lda + i]);
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += log((double)A[i * lda + i]);
   const double t = block_sum(s, red);
   if (threadIdx.x == 0) out[0] += 2.0 * t;
 }
 
 }  // namespace
 
-void launch_fix_diag(double* A, int64_t lda, int n, int nvalid, double add, hipStream_t st) {
-  hipLaunchKernelGGL(fix_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, lda, n, nvalid, add);
+template <typename T>
+void launch_fix_diag(T* A, int64_t lda, int n, int nvalid, double add, hipStream_t st) {
+  hipLaunchKernelGGL(fix_diag_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, lda, n, nvalid, add);
 }
 
-void launch_unpermute_panel(const double* G, double* Pglob, int64_t ldp, int nb, int P, int p,
-                            int nblk, int64_t maxcnt, hipStream_t st) {
+template <typename T>
+void launch_unpermute_panel(const T* G, T* Pglob, int64_t ldp, int nb, int P, int p, int nblk, int64_t maxcnt,
+                            hipStream_t st) {
   const int ntb = nblk - p - 1;
   if (ntb <= 0) return;
-  hipLaunchKernelGGL(unpermute_panel_kernel, dim3(64, (unsigned)ntb), dim3(256), 0, st, G, Pglob, ldp, nb, P, p, maxcnt);
+  hipLaunchKernelGGL(unpermute_panel_kernel<T>, dim3(64, (unsigned)ntb), dim3(256), 0, st, G, Pglob, ldp, nb, P, p, maxcnt);
 }
 
-void launch_pack_rhs_local(const double* y, int64_t n, int k, double* YTloc, int64_t ldy, int nb,
-                           int nlb, int P, int rank, int R, hipStream_t st) {
+template <typename T>
+void launch_pack_rhs_local(const T* y, int64_t n, int k, T* YTloc, int64_t ldy, int nb, int nlb, int P, int rank, int R,
+                           hipStream_t st) {
   if (nlb <= 0) return;
   const int64_t bx = ((int64_t)nlb * nb + 255) / 256;
-  hipLaunchKernelGGL(pack_rhs_local_kernel, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, y, n, k, YTloc, ldy, nb, nlb, P, rank);
+  hipLaunchKernelGGL(pack_rhs_local_kernel<T>, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, y, n, k, YTloc, ldy, nb, nlb, P, rank);
 }
 
-void launch_scatter_local(const double* Loc, int64_t ldl, double* Full, int64_t ldf, int nb, int nlb,
-                          int P, int rank, int R, hipStream_t st) {
+template <typename T>
+void launch_scatter_local(const T* Loc, int64_t ldl, T* Full, int64_t ldf, int nb, int nlb, int P, int rank, int R,
+                          hipStream_t st) {
   if (nlb <= 0) return;
   const int64_t bx = ((int64_t)nlb * nb + 255) / 256;
-  hipLaunchKernelGGL(scatter_local_kernel, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, Loc, ldl, Full, ldf, nb, nlb, P, rank);
+  hipLaunchKernelGGL(scatter_local_kernel<T>, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, Loc, ldl, Full, ldf, nb, nlb, P, rank);
 }
 
-void launch_add_block(double* dst, int64_t ldd, const double* src, int64_t lds, int rows, int cols,
-                      double sign, hipStream_t st) {
+template <typename T>
+void launch_add_block(T* dst, int64_t ldd, const T* src, int64_t lds, int rows, int cols, double sign, hipStream_t st) {
   const int64_t total = (int64_t)rows * cols;
   if (total <= 0) return;
   const int64_t bx = (total + 255) / 256;
-  hipLaunchKernelGGL(add_block_kernel, dim3((unsigned)(bx > 2048 ? 2048 : bx)), dim3(256), 0, st, dst, ldd, src, lds, rows, cols, sign);
+  hipLaunchKernelGGL(add_block_kernel<T>, dim3((unsigned)(bx > 2048 ? 2048 : bx)), dim3(256), 0, st, dst, ldd, src, lds, rows, cols, sign);
 }
 
-void launch_add_scalar(double* p, int64_t count, double v, hipStream_t st) {
+template <typename T>
+void launch_add_scalar(T* p, int64_t count, double v, hipStream_t st) {
   if (count <= 0) return;
   const int64_t bx = (count + 255) / 256;
-  hipLaunchKernelGGL(add_scalar_kernel, dim3((unsigned)(bx > 1024 ? 1024 : bx)), dim3(256), 0, st, p, count, v);
+  hipLaunchKernelGGL(add_scalar_kernel<T>, dim3((unsigned)(bx > 1024 ? 1024 : bx)), dim3(256), 0, st, p, count, v);
 }
 
-void launch_reduce_ranks(const double* src, double* dst, int P, int64_t count, int op, hipStream_t st) {
+template <typename T>
+void launch_reduce_ranks(const T* src, T* dst, int P, int64_t count, int op, hipStream_t st) {
   if (count <= 0) return;
   const int64_t bx = (count + 255) / 256;
-  hipLaunchKernelGGL(reduce_ranks_kernel, dim3((unsigned)(bx > 2048 ? 2048 : bx)), dim3(256), 0, st, src, dst, P, count, op);
+  hipLaunchKernelGGL(reduce_ranks_kernel<T>, dim3((unsigned)(bx > 2048 ? 2048 : bx)), dim3(256), 0, st, src, dst, P, count, op);
 }
 
-void launch_logdet_acc(const double* A, int64_t lda, int n, double* out, hipStream_t st) {
-  hipLaunchKernelGGL(logdet_acc_kernel, dim3(1), dim3(256), 0, st, A, lda, n, out);
+template <typename T>
+void launch_logdet_acc(const T* A, int64_t lda, int n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(logdet_acc_kernel<T>, dim3(1), dim3(256), 0, st, A, lda, n, out);
 }
 
 template <typename T>
@@ -414,7 +424,15 @@ void launch_logdet(const T* A, int64_t lda, int64_t n, double* out, hipStream_t 
   template void launch_var_rows<T>(const T*, int64_t, int64_t, int64_t, double, T*, hipStream_t);   \
   template void launch_logdet<T>(const T*, int64_t, int64_t, double*, hipStream_t);                 \
   template void launch_set_diag_one_t<T>(T*, int64_t, int64_t, hipStream_t);                        \
-  template void launch_copy2d<T>(T*, int64_t, const T*, int64_t, int64_t, int64_t, hipStream_t);
+  template void launch_copy2d<T>(T*, int64_t, const T*, int64_t, int64_t, int64_t, hipStream_t);           \
+  template void launch_fix_diag<T>(T*, int64_t, int, int, double, hipStream_t);                           \
+  template void launch_unpermute_panel<T>(const T*, T*, int64_t, int, int, int, int, int64_t, hipStream_t); \
+  template void launch_pack_rhs_local<T>(const T*, int64_t, int, T*, int64_t, int, int, int, int, int, hipStream_t); \
+  template void launch_scatter_local<T>(const T*, int64_t, T*, int64_t, int, int, int, int, int, hipStream_t); \
+  template void launch_add_block<T>(T*, int64_t, const T*, int64_t, int, int, double, hipStream_t);        \
+  template void launch_add_scalar<T>(T*, int64_t, double, hipStream_t);                                    \
+  template void launch_reduce_ranks<T>(const T*, T*, int, int64_t, int, hipStream_t);                      \
+  template void launch_logdet_acc<T>(const T*, int64_t, int, double*, hipStream_t);
 GPX_INSTANTIATE_MISC(double)
 GPX_INSTANTIATE_MISC(float)
 
