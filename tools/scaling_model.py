@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """PREDICTED multi-GPU budget of the sharded fit + predict — a model, not a measurement:
-no run of this library has ever had more than one physical GPU (SCALE_r01/r02: skipped).  Every input
+no run of this library has ever had more than one physical GPU (SCALE_r01/r02/r03: skipped).  Every input
 is a number measured on ONE MI355X (cited) or a stated assumption about xGMI; when a SCALE record
 exists, the per-term deviations point at the cause.
 
     python tools/scaling_model.py            # prints the markdown tables of DESIGN.md §6
 
-Schedule modelled (csrc/gpx_shard.inc): row blocks of height nb dealt block-cyclically; per panel p
-  main stream      : STRIP(p) -> REST(p)                      (own rows; MFMA-bound)
-  look-ahead stream: after STRIP(p): diagonal block p+1 on its owner -> broadcast [L_pp | inverses | W_p]
-                     -> every rank solves its rows of panel p+1 -> all-gather -> un-permute
-  step time        = STRIP(p) + max(REST(p), chain(p+1))
+Schedule modelled (csrc/gpx_shard.inc, round 4): row blocks of height nb dealt block-cyclically; per panel p
+  main stream      : STRIP_B(p) (own rows below block p+1, its columns) -> REST(p)          (own rows; MFMA-bound)
+  look-ahead stream: STRIP_D(p) (the next diagonal block only, on its owner) -> diagonal block p+1 -> broadcast
+                     [L_pp | inverses | W_p] -> every rank solves its rows of panel p+1 -> all-gather -> un-permute
+  step time        = max(STRIP_B(p) + REST(p), chain(p+1))
+(round 3 ran the whole STRIP first and the chain behind it: STRIP(p) + max(REST(p), chain(p+1)); the table carries that
+fit time in its own column.)
 """
 import json
 
@@ -25,7 +27,8 @@ SOLVE_RATE = 45e12                                  # panel solve as a dense pro
 SOLVE_FLOOR = 0.27e-3                               # one K = 1024 walk of a 128-tile (C2 trace), scales with nb / 1024
 HBM = 3.0e12                                        # un-permute / copy-back rate actually reached by the copy kernels
 PRED_1GPU = {"trsm_rate": 69e12}                    # variance TRSM at M >= 2048 rows (bench: 254 ms for 1.76e13 flop)
-ZSOLVE = 18e-3                                      # z = L^-1 y on the replicated factor
+ZSOLVE = 2.3e-3                                     # z = L^-1 y on the replicated factor: streaming few-right-hand-side solver (round 4; 18 ms before)
+STRIP_D_FLOOR = 45e-6                               # the next diagonal block's update alone: one K = nb walk of 64-tiles (C2 trace: 41-57 us at nb = 1024)
 # ---- assumptions about the fabric (task statement: 7 links x ~153 GB/s per GPU, full mesh) -------------
 LINK = 153e9 * 0.70                                 # sustained per-link payload rate (70 % of peak: assumption)
 LAT = 30e-6                                         # latency of one RCCL collective on the look-ahead stream (assumption)
@@ -46,7 +49,7 @@ def chain_time(idle_work, busy_for):
     return busy_for + idle_work - busy_for / CHAIN_STRETCH
 
 
-def fit_time(N, P, nb=None):
+def fit_time(N, P, nb=None, split=True):
     nb = nb or pick_nb(N, P)
     rate = RATE[nb] if P > 1 else RATE_1GPU
     nblk = N // nb
@@ -68,11 +71,20 @@ def fit_time(N, P, nb=None):
         solve = max(SOLVE_FLOOR * nb / 1024, rows / P * nb * nb / SOLVE_RATE)
         gather = 0.0 if P == 1 else LAT + ag_bytes / P / LINK       # each peer's piece over its own link (full mesh)
         unperm = 0.0 if P == 1 else 2 * ag_bytes / HBM
-        ch = chain_time(diag_idle, rest) + bcast + solve + gather + unperm
         comm_bytes += (bc_bytes + ag_bytes) * (P - 1) / P if P > 1 else 0
-        step = strip + max(rest, ch)
-        if ch > rest:
-            exposed += ch - rest
+        if split:   # round 4: only the next diagonal block's update on the chain; the rest of the strip with the REST
+            strip_d = max(STRIP_D_FLOOR * nb / 1024, nb * (nb + 1.0) * nb / 30e12)
+            strip_b = max(0.0, 2.0 * (n - nb) * nb * nb / P / rate)
+            main = strip_b + rest
+            ch = strip_d + chain_time(diag_idle, main) + bcast + solve + gather + unperm
+            step = max(main, ch)
+            over = ch - main
+        else:
+            ch = chain_time(diag_idle, rest) + bcast + solve + gather + unperm
+            step = strip + max(rest, ch)
+            over = ch - rest
+        if over > 0:
+            exposed += over
             if first_exposed is None:
                 first_exposed = p + 1
         t += step
@@ -101,6 +113,7 @@ def table(N, M, Ps, replicated, label):
     base = None
     for P in Ps:
         f = fit_time(N, P)
+        f["fit_s_round3_schedule"] = fit_time(N, P, split=False)["fit_s"]
         pr = predict_time(N, M, P, replicated and P > 1) if P > 1 else predict_time(N, M, 1, True)
         extra = (ZSOLVE if replicated or P == 1 else 2 * (N // f["nb"]) * (LAT + 35e-6))   # alpha solves (distributed: not overlapped)
         tot = f["fit_s"] + pr + extra
@@ -109,11 +122,11 @@ def table(N, M, Ps, replicated, label):
         rows.append({"P": P, **f, "predict_s": pr, "solves_s": extra, "total_s": tot, "points_per_s": (N + M) / tot,
                      "speedup": base / tot, "efficiency": base / tot / P, "frac_peak": flops / tot / (P * 78.6e12)})
     print(f"\n**{label}** (N = {N}, M = {M})\n")
-    print("| P | nb | fit ms | of which exposed chain ms | chain first exposed at panel | predict ms | solves ms | total ms | points/s | speed-up | efficiency | fraction of P x 78.6 TF | received per rank GB |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| P | nb | fit ms | (round-3 schedule) | of which exposed chain ms | chain first exposed at panel | predict ms | solves ms | total ms | points/s | speed-up | efficiency | fraction of P x 78.6 TF | received per rank GB |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         several = len(rows) > 1
-        cells = [r["P"], r["nb"], f"{r['fit_s'] * 1e3:.0f}", f"{r['exposed_chain_s'] * 1e3:.0f}",
+        cells = [r["P"], r["nb"], f"{r['fit_s'] * 1e3:.0f}", f"{r['fit_s_round3_schedule'] * 1e3:.0f}", f"{r['exposed_chain_s'] * 1e3:.0f}",
                  f"{r['first_exposed_panel']} of {r['panels']}", f"{r['predict_s'] * 1e3:.0f}", f"{r['solves_s'] * 1e3:.0f}",
                  f"{r['total_s'] * 1e3:.0f}", f"{r['points_per_s']:.0f}", f"{r['speedup']:.2f}" if several else "-",
                  f"{r['efficiency']:.2f}" if several else "-", f"{r['frac_peak']:.2f}", f"{r['recv_GB_per_rank']:.1f}"]
