@@ -41,7 +41,7 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                  summed over the launches of that kernel in the timed steps (library events
                  on the library's stream, GPX_FLAG_PROFILE; the last few, under-filled
                  updates of a fit run as 64-tiles — another kernel — and are not counted)
-  fit_predict_one_pass — the same step as ONE call (``gp.fit_predict`` -> gpx_fit_predict, ABI v4: the query rows ride
+  fit_predict_one_pass — the same step as ONE call (``gp.fit_predict`` -> gpx_fit_predict, ABI v4+: the query rows ride
                  through the factorisation), a few steps after the timed region; reported beside the headline,
                  never ``value``
   cpu_baseline — the NumPy/SciPy oracle (oracle/gp_oracle.py) on the GPU box's host cores.
@@ -486,8 +486,6 @@ def run(args):
         N = 8192
     if args.workload == "C5":
         lengthscale = (0.3, 0.2, 0.25)              # ARD
-    if dtype != "float64" and (world > 1 or args.mode in ("shard", "group")):
-        raise SystemExit("--dtype float32 / mixed: unsharded handles only")
     tdt = torch.float32 if dtype == "float32" else torch.float64
     peak_mfma = PEAK_FP64_MFMA_TFLOPS if dtype == "float64" else PEAK_FP32_MFMA_TFLOPS   # the factorisation's engine
     if args.workload == "C4":
@@ -507,10 +505,10 @@ def run(args):
         if rank == 0:
             devs = [args.device] * world if args.device is not None else list(range(world))
             gp = GP(kernel, lengthscale, SF2, SN2, jitter=0.0, block=args.block, profile=True, devices=devs,
-                    transport="local", oversubscribe=args.device is not None)
+                    transport="local", oversubscribe=args.device is not None, dtype=dtype)
     elif shard:
         gp = GP(kernel, lengthscale, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True,
-                world=world, rank=rank, comm="rccl" if args.backend == "nccl" else "host")
+                world=world, rank=rank, comm="rccl" if args.backend == "nccl" else "host", dtype=dtype)
     else:
         gp = GP(kernel, lengthscale, SF2, SN2, jitter=0.0, device=local, block=args.block, profile=True, dtype=dtype)
     beat(args, "communicator + inputs")
@@ -581,7 +579,7 @@ def run(args):
                 else:
                     t_plain += time.perf_counter() - t1
         unprofiled_ms = (t_plain * 1e3 / nrep, t_prof * 1e3 / nrep)
-        # the ONE-PASS form of the same step (GP.fit_predict -> gpx_fit_predict, ABI v4: the query points' cross-kernel
+        # the ONE-PASS form of the same step (GP.fit_predict -> gpx_fit_predict, ABI v4+: the query points' cross-kernel
         # rows ride through the factorisation as bordered rows): reported beside the headline, never `value`
         one_pass = None
         if dtype in ("float64", "float32") and M <= 8192:
@@ -602,17 +600,26 @@ def run(args):
         # the sharded posterior against the single-GPU path on the same inputs (rank 0's GPU)
         verdict = [None]
         if rank == 0:
-            with GP(kernel, lengthscale, SF2, SN2, jitter=0.0, device=local, block=args.block) as one:
+            with GP(kernel, lengthscale, SF2, SN2, jitter=0.0, device=local, block=args.block, dtype=dtype) as one:
                 m1, v1 = one.fit(Xd, yd).predict(Xsd)
             # north_star's elementwise criterion (1e-6) between two different blockings of the
-            # same factorisation, plus the error relative to the largest posterior mean
+            # same factorisation, plus the error relative to the largest posterior mean.  fp32 / mixed shards are
+            # compared with the unsharded handle of the same dtype at that dtype's level (fp32-grade quantities:
+            # 5e-3 of the largest mean / of sf2; the mixed mode's fp64-grade mean: 1e-6 elementwise)
             em = float(((mean - m1).abs() / m1.abs().clamp_min(1e-6)).max().item())
             ev = float(((var - v1).abs() / v1.clamp_min(1e-6 * SF2)).max().item())
             es = float(((mean - m1).abs().max() / m1.abs().max()).item())
+            evs = float(((var - v1).abs().max() / SF2))
             del m1, v1
-            verdict[0] = {"vs": "single-GPU path, same inputs", "mean_max_rel": em, "var_max_rel": ev,
-                          "mean_err_over_max_mean": es, "tol": 1e-6,
-                          "ok": bool(em < 1e-6 and ev < 1e-6 and ok)}
+            if dtype == "float64":
+                good = em < 1e-6 and ev < 1e-6
+            elif dtype == "mixed":
+                good = em < 1e-6 and evs < 5e-3
+            else:
+                good = es < 5e-3 and evs < 5e-3
+            verdict[0] = {"vs": f"single-GPU path ({dtype}), same inputs", "mean_max_rel": em, "var_max_rel": ev,
+                          "mean_err_over_max_mean": es, "var_err_over_sf2": evs, "tol": 1e-6 if dtype == "float64" else 5e-3,
+                          "ok": bool(good and ok)}
         if world > 1:
             dist.broadcast_object_list(verdict, src=0)
         shard_check = verdict[0]
@@ -683,8 +690,8 @@ def run(args):
         if shard:   # the sharded update has no per-launch flop bookkeeping: rate the whole factorisation
             out["roofline"].update(kernel="blocked Cholesky, all ranks (gemm_nt_kernel<128> with block-cyclic mask)",
                                    traffic=None, traffic_source=None,
-                                   achieved=out["cholesky_tflops"], peak=PEAK_FP64_MFMA_TFLOPS * world,
-                                   frac=out["cholesky_tflops"] / (PEAK_FP64_MFMA_TFLOPS * world))
+                                   achieved=out["cholesky_tflops"], peak=peak_mfma * world,
+                                   frac=out["cholesky_tflops"] / (peak_mfma * world))
         if world == 1 and not args.no_microbench:
             import ctypes as C
             a, b = C.c_double(0), C.c_double(0)
