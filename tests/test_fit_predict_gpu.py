@@ -25,6 +25,8 @@ def rel(a, b, floor):
     (1024, 64, 2, 1, "rbf", False, 0),          # a single panel: no trailing update at all
     (5000, 1, 3, 1, "rbf", False, 256),         # one query point
     (4224, 8192, 3, 2, "rbf", True, 0),         # as many query points as one predict batch holds
+    (1000, 3000, 3, 1, "matern52", False, 256), # round 4: more query rows than matrix rows (the bordered part is the larger one)
+    (700, 300, 2, 64, "rbf", False, 128),       # round 4: all 64 right-hand-side rows in use beside the query rows
 ])
 def test_fit_predict_matches_the_oracle_and_the_two_calls(N, M, d, k, kernel, ard, block):
     X, y, Xs = synthetic_problem(N, d, M, seed=N + M)
