@@ -41,7 +41,8 @@ class GP:
         tests/test_full_size_gpu.py) but an **fp32-grade variance** — sf2 - ||L^-1 k*||^2 through
         the fp32 factor is never refined, so it carries absolute errors of ~3e-6 sf2, which is
         percents of a variance of 1e-4 sf2; use "float64" when the variance matters.  At most 8
-        targets)
+        targets).  Every dtype also runs sharded (``devices=`` / ``world=``: the shard takes the handle's
+        element type; round 4)
     refine : "mixed" only — 0 (default): refine until ||y - K alpha|| <= 1e-10 ||y|| or the residual
         stops contracting (at most 12 iterations; ``timings_["refine_iters"]`` says how many ran);
         n > 0: exactly n iterations

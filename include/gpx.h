@@ -66,7 +66,7 @@ typedef struct gpx_handle gpx_handle;
 
 typedef struct gpx_config {
   int32_t kernel;  /* GPX_KERNEL_*                                   */
-  int32_t dtype;   /* GPX_F64 | GPX_F32                              */
+  int32_t dtype;   /* GPX_F64 | GPX_F32 | GPX_MIXED                  */
   int32_t device;  /* HIP device ordinal this handle computes on (ndev <= 1)                 */
   int32_t block;   /* Cholesky panel width nb (multiple of 128, <= 2048), 0 = default (1024) */
   int32_t rank;    /* process-per-GPU shard: this process' rank (0 if world==1)              */
@@ -123,8 +123,10 @@ const char* gpx_last_error(gpx_handle* h); /* h may be NULL: last error of gpx_c
 /* K = sf2 k(X,X) + (sn2+jitter) I;  L = chol(K);  alpha = L^-T L^-1 y.
  * X (N,d), y (N,k) row-major, in the dtype of the handle (GPX_F64 and GPX_MIXED: double,
  * GPX_F32: float — everything including the factorisation then runs in fp32: config 5, the
- * precision study; GPX_MIXED: fp32 factorisation + fp64 refinement, k <= 8; both unsharded
- * handles only).  lengthscale: n_ls = 1 or d. */
+ * precision study; GPX_MIXED: fp32 factorisation + fp64 refinement, k <= 8).  ABI v5: every dtype also on
+ * a shard / device group (the row-block shard runs in the handle's element type; the mixed mode's fp64
+ * refinement is replicated work on every rank, its fp32 solves local on a replicated factor and collective
+ * on a factor that is only held distributed).  lengthscale: n_ls = 1 or d. */
 int gpx_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
             const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter,
             int32_t mem_kind, int64_t* info);
