@@ -216,7 +216,7 @@ def cpu_sample(n_sample, threads):
             "extrapolated_points_per_s_at_workload": (N_TRAIN + M_TEST) / est}
 
 
-def cpu_baseline(mode="auto", n_sample=24576, full_timeout_s=420.0):
+def cpu_baseline(mode="auto", n_sample=24576, full_timeout_s=330.0):
     """`value` = the oracle's fit+predict rate AT THE WORKLOAD (N=65536) on THIS host's cores.
 
     mode "auto" (default): measured IN THIS RUN at full size (the GPU side is finished by then; ~2 min with 16

@@ -79,6 +79,30 @@ def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N, repl):
     assert np.array_equal(res[0]["mean"], res[-1]["mean"]) and np.array_equal(res[0]["var"], res[-1]["var"])
 
 
+@pytest.mark.parametrize("world,dtype,nb,N,repl", [(2, "float32", 128, 700, 0), (3, "float32", 256, 2000, 1),
+                                                   (2, "mixed", 128, 1500, 0), (3, "mixed", 256, 2000, 1)])
+def test_fp32_and_mixed_shards_over_the_host_transport(tmp_path, world, dtype, nb, N, repl):
+    """Round 4: the shard in the handle's element type, one PROCESS per rank over the host transport — whose callbacks
+    reduce doubles (include/gpx.h: gpx_host_comm), so fp32 reductions are widened and narrowed on the host.  fp32 at the
+    precision study's level, mixed at 1e-6 on the mean / 1e-7 on alpha against the fp64 oracle; identical on every rank."""
+    env = {"SHARD_KERNEL": "rbf", "SHARD_NB": str(nb), "SHARD_N": str(N), "SHARD_DTYPE": dtype, "GPX_SHARD_REPLICATE": str(repl)}
+    res = run_ranks("gpu", world, tmp_path, env, timeout=600)
+    X, y, Xs = synthetic_problem(N, 3, 90, seed=77)
+    ref = OracleGP("rbf", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    for r in res:
+        assert int(r["info"]) == 0
+        em = np.max(np.abs(r["mean"] - mr) / np.maximum(np.abs(mr), 1e-6))
+        es = np.max(np.abs(r["mean"] - mr)) / np.max(np.abs(mr))
+        ea = np.max(np.abs(r["alpha"] - ref.alpha_)) / np.max(np.abs(ref.alpha_))
+        ev = np.max(np.abs(r["var"] - vr)) / 1.5
+        if dtype == "mixed":
+            assert em <= 1e-6 and ea <= 1e-7 and ev <= 2e-3, (em, ea, ev)
+        else:
+            assert es <= 2e-3 and ev <= 2e-3 and ea <= 5e-2, (es, ea, ev)
+    assert np.array_equal(res[0]["mean"], res[-1]["mean"]) and np.array_equal(res[0]["var"], res[-1]["var"])
+
+
 @pytest.mark.parametrize("world,N,nbp", [(2, 1500, 256), (3, 1100, 128)])
 def test_sharded_lml_gradient_over_host_transport(tmp_path, world, N, nbp):
     """gpx_lml_grad on a row-block shard (one process per rank, host transport): L^-T in row blocks
