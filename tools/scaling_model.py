@@ -27,6 +27,9 @@ SOLVE_RATE = 45e12                                  # panel solve as a dense pro
 SOLVE_FLOOR = 0.27e-3                               # one K = 1024 walk of a 128-tile (C2 trace), scales with nb / 1024
 HBM = 3.0e12                                        # un-permute / copy-back rate actually reached by the copy kernels
 PRED_1GPU = {"trsm_rate": 69e12}                    # variance TRSM at M >= 2048 rows (bench: 254 ms for 1.76e13 flop)
+# predict of few query points against the whole N = 65536 factor, one card (tools/predict_rows.py, profiles/r04_predict_rows.txt):
+# rows -> achieved flop/s of N^2 rows / time (the per-rank share of a replicated shard: 512 rows at P = 8)
+PRED_ROWS_TF = {128: 34.5e12, 256: 44.7e12, 512: 52.4e12, 1024: 63.6e12, 2048: 67.3e12, 4096: 70.2e12, 8192: 70.9e12}
 ZSOLVE = 2.3e-3                                     # z = L^-1 y on the replicated factor: streaming few-right-hand-side solver (round 4; 18 ms before)
 STRIP_D_FLOOR = 45e-6                               # the next diagonal block's update alone: one K = nb walk of 64-tiles (C2 trace: 41-57 us at nb = 1024)
 # ---- assumptions about the fabric (task statement: 7 links x ~153 GB/s per GPU, full mesh) -------------
@@ -95,8 +98,8 @@ def fit_time(N, P, nb=None, split=True):
 def predict_time(N, M, P, replicated):
     if replicated:                                   # rank r: M / P query points against the whole factor
         rows = max(128, -(-M // P // 128) * 128)
-        eff = min(1.0, (rows / 2048.0) ** 0.5)       # small row counts fill the chip badly (C2: 55 TF at 4096 x 8192)
-        return N * N * rows / (PRED_1GPU["trsm_rate"] * eff) + 1.5e-3 + (0 if P == 1 else LAT)
+        key = min(PRED_ROWS_TF, key=lambda r: abs(r - rows))   # measured rate at the nearest row count
+        return N * N * rows / PRED_ROWS_TF[key] + 1.5e-3 + (0 if P == 1 else LAT)
     nb = pick_nb(N, P)                               # distributed variance solve: one (M x nb) broadcast per block, hidden
     rate = RATE[nb]                                  # behind the rest of the previous update when it is long enough
     t = 0.0
