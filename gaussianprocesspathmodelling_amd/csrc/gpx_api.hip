@@ -1807,22 +1807,45 @@ int gpx_fit_predict(gpx_handle* h, const void* X, const void* y, int64_t N, int3
   for (int i = 0; i < n_ls; ++i)
     if (!(lengthscale[i] > 0.0)) return fail(h, GPX_E_ARG, "gpx_fit_predict: lengthscale must be > 0");
   if (N > (int64_t)INT_MAX - 4096) return fail(h, GPX_E_ARG, "gpx_fit_predict: N too large");
-  // one device, one precision: groups, shards and the mixed mode factor and predict in separate calls
-  if (h->group || h->cfg.world > 1 || h->comm || h->cfg.dtype == GPX_MIXED)
-    return fail(h, GPX_E_UNSUPPORTED, "gpx_fit_predict: single-device fp64 / fp32 handles only (use gpx_fit + gpx_predict)");
-  if (M > pred_batch_rows(h, round_up(M, TILE), 0, false))
-    return fail(h, GPX_E_UNSUPPORTED, "gpx_fit_predict: more query points than one predict batch (use gpx_fit + gpx_predict)");
+  // Groups, shards and the mixed mode have no bordered query rows: for them the call IS the two calls (same results;
+  // ABI v5 — it was GPX_E_UNSUPPORTED).  *info > 0: not positive definite, nothing predicted.
+  if (h->group || h->cfg.world > 1 || h->comm || h->cfg.dtype == GPX_MIXED) {
+    const int rc2 = gpx_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
+    if (rc2 != GPX_OK || *info != 0) return rc2;
+    return gpx_predict(h, Xq, M, mean, var, mem_kind);
+  }
+  // one batch of query points rides through the factorisation; more than that (ABI v5: it was GPX_E_UNSUPPORTED): the
+  // first batch rides, the others go through the ordinary predict against the factor the pass leaves behind — query
+  // rows are independent, so the split changes no bit of either part
+  const int64_t Mb = std::min<int64_t>(M, pred_batch_rows(h, round_up(M, TILE), 0, false));
   HIPCHK(h, hipSetDevice(h->cfg.device));
   h->fitted = false;
   h->err.clear();
   h->phases.clear();
   h->ev_used = 0;
+  const size_t es = h->cfg.dtype == GPX_F32 ? sizeof(float) : sizeof(double);
   int rc = h->cfg.dtype == GPX_F32
-               ? fit_impl<float>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info, Xq, M)
-               : fit_impl<double>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info, Xq, M);
+               ? fit_impl<float>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info, Xq, Mb)
+               : fit_impl<double>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info, Xq, Mb);
   if (rc != GPX_OK || !h->fitted) return rc;  // *info > 0: not positive definite, nothing predicted
-  return h->cfg.dtype == GPX_F32 ? fused_predict_tail<float>(h, M, mean, var, mem_kind)
-                                 : fused_predict_tail<double>(h, M, mean, var, mem_kind);
+  rc = h->cfg.dtype == GPX_F32 ? fused_predict_tail<float>(h, Mb, mean, var, mem_kind)
+                               : fused_predict_tail<double>(h, Mb, mean, var, mem_kind);
+  if (rc != GPX_OK || Mb == M) return rc;
+  const gpx_timings first = h->tm;  // the rest through predict; its clocks are added to the pass's
+  h->phases.clear();
+  h->ev_used = 0;
+  const void* Xr = (const char*)Xq + (size_t)Mb * d * es;
+  void* mr = (char*)mean + (size_t)Mb * k * es;
+  void* vr = var ? (char*)var + (size_t)Mb * es : nullptr;
+  rc = h->cfg.dtype == GPX_F32 ? predict_impl<float>(h, Xr, M - Mb, mr, vr, mem_kind)
+                               : predict_impl<double>(h, Xr, M - Mb, mr, vr, mem_kind);
+  h->tm.kstar += first.kstar;
+  h->tm.mean += first.mean;
+  h->tm.trsm += first.trsm;
+  h->tm.var += first.var;
+  h->tm.d2h += first.d2h;
+  h->tm.predict_total += first.predict_total;
+  return rc;
 }
 GPX_CATCH_ALL
 
