@@ -101,3 +101,28 @@ def test_four_devices_match_the_single_gpu_path(transport):
         mean, var = gp.fit(X, y).predict(Xs)
     assert np.max(np.abs(mean - m1) / np.maximum(np.abs(m1), 1e-6)) <= 1e-8
     assert np.max(np.abs(var - v1) / np.maximum(v1, 1.5e-6)) <= 1e-8
+
+
+@needs2
+@pytest.mark.parametrize("transport", ["local", "rccl"])
+@pytest.mark.parametrize("dtype,repl", [("float32", "1"), ("float32", "0"), ("mixed", "1"), ("mixed", "0")])
+def test_two_devices_fp32_and_mixed_shards(monkeypatch, transport, dtype, repl):
+    """Round 4: the shard in the handle's element type across two REAL devices — typed RCCL reductions (ncclFloat), byte
+    broadcasts / all-gathers, the in-process transport's float sum kernel over peer copies; mixed: the fp64 refinement
+    replicated on both cards with local (replicated factor) or collective (distributed factor) fp32 solves."""
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", repl)
+    monkeypatch.setenv("GPX_NB_SHARD", "256")
+    X, y, Xs = synthetic_problem(4000, 3, 300, seed=25)
+    ref = OracleGP("rbf", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    Xi, yi, Xsi = (v.astype(np.float32) for v in (X, y, Xs)) if dtype == "float32" else (X, y, Xs)
+    with GP("rbf", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0, dtype=dtype, devices=[0, 1], transport=transport) as gp:
+        mean, var = gp.fit(Xi, yi).predict(Xsi)
+        assert gp.info_ == 0
+        ev = np.max(np.abs(var - vr)) / 1.5
+        if dtype == "mixed":
+            em = np.max(np.abs(mean - mr) / np.maximum(np.abs(mr), 1e-6))
+            ea = np.max(np.abs(gp.alpha_ - ref.alpha_)) / np.max(np.abs(ref.alpha_))
+            assert em <= 1e-6 and ea <= 1e-7 and ev <= 2e-3
+        else:
+            assert np.max(np.abs(mean - mr)) <= 2e-3 * np.max(np.abs(mr)) and ev <= 2e-3
