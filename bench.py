@@ -658,7 +658,8 @@ def run(args):
             "config": {"workload": f"{args.workload}: exact GP fit+predict, N={N} d={DIM} {kernel} "
                                    f"{'ARD ' if args.workload == 'C5' else ''}{dtype}, M={M}, inputs resident in HBM",
                        "N": N, "d": DIM, "M": M, "lengthscale": lengthscale,
-                       "kernel": kernel, "block": args.block or (shard_block(N, world) if shard else 1024),
+                       "kernel": kernel, "block": args.block or (shard_block(N, world) if shard else
+                                                                (2048 if N >= int(os.environ.get("GPX_NB_WIDE_FROM", "40960") or 0) > 0 else 1024)),
                        "parallelism": "1 gpu" if world == 1 else
                        (f"row-block-cyclic shard over {world} gpus (one process, in-process peer-copy transport)" if group else
                         f"row-block-cyclic shard over {world} gpus ({'RCCL' if args.backend == 'nccl' else 'host collectives, rehearsal'})" if shard

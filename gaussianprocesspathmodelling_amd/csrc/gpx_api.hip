@@ -73,7 +73,8 @@ struct gpx_handle {
   gpx_config cfg{};
   int nb = 1024;       // Cholesky panel width
   int nb_solve = 256;  // block width of the alpha solves (one 64-row slab: latency-bound)
-  int nb_pred = 1024;  // block width of the variance TRSM
+  int nb_pred = 1024;  // block width of the variance TRSM (follows the panel width when the library chooses that: auto_panel_width)
+  bool nb_pred_env = false;  // GPX_NB_PRED given: never overridden
   hipStream_t st = nullptr;   // main stream
   hipStream_t st2 = nullptr;  // look-ahead (panel) stream, high priority
   hipStream_t st3 = nullptr;  // side stream of the diagonal chain: in-block SYRKs, block inverses
@@ -970,6 +971,20 @@ int64_t pred_batch_rows(gpx_handle* h, int64_t Mpad, size_t row_bytes, bool may_
   return std::min(cap, Mpad);
 }
 
+// Panel width the library picks when gpx_config.block == 0 (round 4).  Rounds 1-3 swept 256 ... 2048 and found a plateau
+// from 1024 — with the diagonal chain partly exposed.  On the round-3/4 schedule nothing of the chain is exposed at large
+// N, and a 2048-wide panel halves the number of trailing updates (K = 2048 per tile: the per-tile prologue + epilogue
+// weigh half as much, 72.4 against 71.7 TF) and of block steps of the variance solve: C3 1602-1605 -> 1579-1584 ms, C5 fp32
+// 881 -> 859 ms; equal at N = 16384 ... 32768, slower at N = 8192 where the chain sets the pace (12.5 vs 13.2 ms):
+// tools/r04_nb_sweep.sh, profiles/r04_panel_width.txt.  GPX_NB_WIDE_FROM = rows from which 2048 is used (0: never).
+int auto_panel_width(int64_t Npad) {
+  static const int64_t from = [] {
+    const char* e = getenv("GPX_NB_WIDE_FROM");
+    return e ? (int64_t)atoll(e) : (int64_t)40960;
+  }();
+  return (from > 0 && Npad >= from) ? 2048 : 1024;
+}
+
 template <typename T>
 int predict_core(gpx_handle* h, const void* Xq, int64_t M, bool want_var, int32_t mem_kind);
 bool few_solver_applies(const gpx_handle* h);
@@ -995,6 +1010,10 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
   const int64_t Npad = round_up(N, TILE);
   const int64_t Mpad = Xq ? round_up(M, TILE) : 0;
   const int64_t ld = Npad + ld_skew<T>();
+  if (h->cfg.block == 0) {  // the library's choice; predict's block solves use the fit's block inverses: same width
+    h->nb = auto_panel_width(Npad);
+    if (!h->nb_pred_env) h->nb_pred = h->nb;
+  }
   const int64_t ldp = h->nb + ld_skew<T>();
   h->N = N; h->Npad = Npad; h->ld = ld; h->ldp = ldp; h->d = d; h->k = k; h->n_ls = n_ls;
   h->sf2 = sf2; h->sn2 = sn2; h->jitter = jitter;
@@ -1113,7 +1132,14 @@ int fit_impl(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, 
 // RT (k <= 8 rows of ld) <- (L L^T)^-1 RT (or only L^-T RT) with the fit's explicit block inverses: a forward and a
 // backward block substitution as streams over the factor (gpx_mixed.hip: rowdot / coldot kernels), one stream, in order.
 template <typename T>
-int solve_few(gpx_handle* h, T* RT, int k, const T* L, int64_t ld, int64_t n, const T* W, int nb, bool forward, bool backward) {
+int solve_few(gpx_handle* h, T* RT, int k, const T* L, int64_t ld, int64_t n, const T* W, int nbw, bool forward, bool backward) {
+  // W: [n / nbw][nbw][nbw] explicit inverses of the nbw-wide diagonal blocks.  The sweeps run in blocks of nb = min(nbw,
+  // 1024): the diagonal nb-sub-blocks of a lower-triangular inverse ARE the inverses of the diagonal nb-sub-blocks of
+  // the factor, so a 2048-wide W serves 1024-blocks through a pointer and its leading dimension (round 4).
+  const int nb = std::min(nbw, 1024);
+  auto Wsub = [&](int64_t o) -> const T* {
+    return W + (o / nbw) * (int64_t)nbw * nbw + ((o % nbw) / nb) * ((int64_t)nb * nbw + nb);
+  };
   int rc;
   if ((rc = ensure(h, h->Zfew, (size_t)8 * nb * sizeof(T)))) return rc;
   T* Zs = (T*)h->Zfew.p;
@@ -1121,14 +1147,14 @@ int solve_few(gpx_handle* h, T* RT, int k, const T* L, int64_t ld, int64_t n, co
   for (int64_t o = 0; forward && o < n; o += nb) {  // L z = r
     const int nbp = (int)std::min<int64_t>(nb, n - o);
     const int64_t t0 = o + nbp;
-    launch_few_product<T>(false, true, Zs, nb, W + (o / nb) * (int64_t)nb * nb, nb, nbp, nbp, RT + o, ld, k, st);
+    launch_few_product<T>(false, true, Zs, nb, Wsub(o), nbw, nbp, nbp, RT + o, ld, k, st);
     HIPCHK(h, hipMemcpy2DAsync(RT + o, (size_t)ld * sizeof(T), Zs, (size_t)nb * sizeof(T), (size_t)nbp * sizeof(T), k,
                                hipMemcpyDeviceToDevice, st));
     launch_few_product<T>(false, false, RT + t0, ld, L + t0 * ld + o, ld, n - t0, nbp, Zs, nb, k, st);
   }
   for (int64_t o = ((n - 1) / nb) * nb; backward && o >= 0; o -= nb) {  // L^T x = z
     const int nbp = (int)std::min<int64_t>(nb, n - o);
-    launch_few_product<T>(true, true, Zs, nb, W + (o / nb) * (int64_t)nb * nb, nb, nbp, nbp, RT + o, ld, k, st);
+    launch_few_product<T>(true, true, Zs, nb, Wsub(o), nbw, nbp, nbp, RT + o, ld, k, st);
     HIPCHK(h, hipMemcpy2DAsync(RT + o, (size_t)ld * sizeof(T), Zs, (size_t)nb * sizeof(T), (size_t)nbp * sizeof(T), k,
                                hipMemcpyDeviceToDevice, st));
     launch_few_product<T>(true, false, RT, ld, L + o * ld, ld, o, nbp, Zs, nb, k, st);
@@ -1141,7 +1167,7 @@ int solve_few(gpx_handle* h, T* RT, int k, const T* L, int64_t ld, int64_t n, co
 // slab path)
 bool few_solver_applies(const gpx_handle* h) {
   const char* e = getenv("GPX_FEW_SOLVE");
-  return (!e || atoi(e) != 0) && h->nbw > 0 && h->nbw <= 1024 && h->nbw % 128 == 0 && h->k <= 8 &&
+  return (!e || atoi(e) != 0) && h->nbw > 0 && (h->nbw <= 1024 ? h->nbw % 128 == 0 : h->nbw % 1024 == 0) && h->k <= 8 &&
          (!h->comm || h->repl) && h->Wblk.p;
 }
 
@@ -1354,7 +1380,7 @@ int lml_grad_impl(gpx_handle* h, double* lml, double* grad) {
   const int d = h->d, k = h->k, ntheta = h->n_ls + 2, ard = h->n_ls > 1;
   Comm* cm = h->comm;
   const int P = cm ? cm->world : 1, rank = cm ? cm->rank : 0;
-  const int nb = h->nb_pred;
+  const int nb = std::min(h->nb_pred, 1024);  // the gradient's sweeps keep their measured 1024-blocks whatever the fit's panel width
   gpx_timings& tm = h->tm;
   tm.grad_trtri = tm.grad_trace = tm.grad_total = 0;
   const int64_t s1n = kinv_trace_slots(Npad), s2n = alpha_quad_slots(Npad);
@@ -1681,8 +1707,8 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) try {
   if (cfg->ndev < 0 || cfg->ndev > GPX_MAX_GROUP)
     return fail(nullptr, GPX_E_ARG, "gpx_create: need 0 <= ndev <= GPX_MAX_GROUP");
   const int nb = cfg->block == 0 ? 1024 : cfg->block;
-  if (nb < 128 || nb > 2048 || nb % 128 != 0)
-    return fail(nullptr, GPX_E_ARG, "gpx_create: block must be a multiple of 128 in [128, 2048]");
+  if (nb < 128 || nb > 4096 || nb % 128 != 0)
+    return fail(nullptr, GPX_E_ARG, "gpx_create: block must be a multiple of 128 in [128, 4096]");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, GPX_E_HIP, "gpx_create: no HIP device visible (libgpx has no CPU fallback)");
@@ -1710,10 +1736,11 @@ int gpx_create(gpx_handle** out, const gpx_config* cfg) try {
   auto block_env = [](const char* name, int dflt) {
     const char* e = getenv(name);
     const int v = e ? atoi(e) : dflt;
-    return (v >= 128 && v <= 2048 && v % 128 == 0) ? v : dflt;
+    return (v >= 128 && v <= 4096 && v % 128 == 0) ? v : dflt;
   };
   h->nb_solve = block_env("GPX_NB_SOLVE", h->nb_solve);
   h->nb_pred = block_env("GPX_NB_PRED", h->nb_pred);
+  h->nb_pred_env = getenv("GPX_NB_PRED") != nullptr;
   int prio_lo = 0, prio_hi = 0;
   if (hipSetDevice(device) != hipSuccess ||
       hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess ||

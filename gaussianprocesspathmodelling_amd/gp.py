@@ -59,7 +59,8 @@ class GP:
         devices are distinct, else local.
     oversubscribe : allow ``devices=n`` with fewer than n GPUs visible: ordinals wrap around, so
         several ranks share a GPU over the local transport (how the one-GPU tests run 2..8 ranks)
-    block : Cholesky panel width nb (multiple of 128, at most 2048; 0 = library default 1024)
+    block : Cholesky panel width nb (multiple of 128, at most 4096; 0 = the library's choice: 1024, and 2048 from
+        N = 40960 on, where nothing of the serial chain is exposed any more)
     max_tries : jitter escalations (x10 each) before ``LinAlgError``
     profile : record per-launch timings of the Cholesky sub-phases
     world, rank : row-block shard of ONE Gram matrix over ``world`` processes (one per GPU).

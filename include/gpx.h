@@ -68,7 +68,7 @@ typedef struct gpx_config {
   int32_t kernel;  /* GPX_KERNEL_*                                   */
   int32_t dtype;   /* GPX_F64 | GPX_F32 | GPX_MIXED                  */
   int32_t device;  /* HIP device ordinal this handle computes on (ndev <= 1)                 */
-  int32_t block;   /* Cholesky panel width nb (multiple of 128, <= 2048), 0 = default (1024) */
+  int32_t block;   /* Cholesky panel width nb (multiple of 128, <= 4096), 0 = the library's choice: 1024; 2048 from N = 40960 on */
   int32_t rank;    /* process-per-GPU shard: this process' rank (0 if world==1)              */
   int32_t world;   /* process-per-GPU shard: number of processes sharing the Gram matrix     */
   int32_t flags;   /* GPX_FLAG_*                                     */
