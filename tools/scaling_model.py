@@ -99,7 +99,10 @@ def predict_time(N, M, P, replicated):
     if replicated:                                   # rank r: M / P query points against the whole factor
         rows = max(128, -(-M // P // 128) * 128)
         key = min(PRED_ROWS_TF, key=lambda r: abs(r - rows))   # measured rate at the nearest row count
-        return N * N * rows / PRED_ROWS_TF[key] + 1.5e-3 + (0 if P == 1 else LAT)
+        rate = PRED_ROWS_TF[key]
+        if P > 1 and pick_nb(N, P) == 512 and key == 512:      # the shard's 512-blocks: 46.45 ms for 512 rows (r04_predict_block_ab.txt)
+            rate = N * N * 512 / 46.45e-3
+        return N * N * rows / rate + 1.5e-3 + (0 if P == 1 else LAT)
     nb = pick_nb(N, P)                               # distributed variance solve: one (M x nb) broadcast per block, hidden
     rate = RATE[nb]                                  # behind the rest of the previous update when it is long enough
     t = 0.0
