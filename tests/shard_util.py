@@ -17,10 +17,24 @@ def free_port():
 def run_ranks(mode, world, tmp_path, env_extra=None, timeout=300):
     """Launch `world` worker processes on 127.0.0.1 and return their result dicts.  Worker output
     goes to files (a full pipe would block a rank inside a collective); a rank that dies takes the
-    others down at once instead of leaving them waiting for it in a collective until the timeout."""
+    others down at once instead of leaving them waiting for it in a collective until the timeout.
+    The rendezvous port is probed, then used: if somebody took it in between (EADDRINUSE in a rank's log — seen once
+    on a shared box) the launch is repeated on another port, at most three times."""
+    last = None
+    for attempt in range(3):
+        try:
+            return _run_ranks_once(mode, world, tmp_path, env_extra, timeout, attempt)
+        except AssertionError as e:
+            last = e
+            if "EADDRINUSE" not in str(e):
+                raise
+    raise last
+
+
+def _run_ranks_once(mode, world, tmp_path, env_extra, timeout, attempt):
     import time
     port = free_port()
-    out = os.path.join(str(tmp_path), f"{mode}_w{world}")
+    out = os.path.join(str(tmp_path), f"{mode}_w{world}" + (f"_try{attempt}" if attempt else ""))
     procs, logf = [], []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
