@@ -1380,7 +1380,12 @@ int lml_grad_impl(gpx_handle* h, double* lml, double* grad) {
   const int d = h->d, k = h->k, ntheta = h->n_ls + 2, ard = h->n_ls > 1;
   Comm* cm = h->comm;
   const int P = cm ? cm->world : 1, rank = cm ? cm->rank : 0;
-  const int nb = std::min(h->nb_pred, 1024);  // the gradient's sweeps keep their measured 1024-blocks whatever the fit's panel width
+  // the gradient's sweeps keep their measured 1024-blocks whatever the fit's panel width (GPX_NB_GRAD overrides: A/B)
+  const int nb = [&] {
+    const char* e = getenv("GPX_NB_GRAD");
+    const int v = e ? atoi(e) : 0;
+    return (v >= 128 && v <= 4096 && v % 128 == 0) ? v : std::min(h->nb_pred, 1024);
+  }();
   gpx_timings& tm = h->tm;
   tm.grad_trtri = tm.grad_trace = tm.grad_total = 0;
   const int64_t s1n = kinv_trace_slots(Npad), s2n = alpha_quad_slots(Npad);
