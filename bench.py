@@ -356,20 +356,28 @@ def launch_ranks(n):
     path as under the driver's own launcher: the JSON line is rank 0's."""
     import socket
     import subprocess
-    with socket.socket() as s:                 # a port nobody listens on right now
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL between processes)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
-    child = subprocess.Popen(cmd, env=env)
-    try:
-        return child.wait()
-    except KeyboardInterrupt:
-        child.terminate()
-        return child.wait()
+    rc = 1
+    for attempt in range(2):
+        with socket.socket() as s:             # a port nobody listens on right now
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+        t0 = time.time()
+        child = subprocess.Popen(cmd, env=env)
+        try:
+            rc = child.wait()
+        except KeyboardInterrupt:
+            child.terminate()
+            return child.wait()
+        # a launch that dies within seconds never got to the GPUs — typically the rendezvous port was taken between the
+        # probe and its use: once more on another port, then the code is the answer
+        if rc == 0 or time.time() - t0 > 20.0:
+            break
+    return rc
 
 
 def beat(args, what):
