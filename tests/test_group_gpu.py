@@ -346,3 +346,34 @@ def test_group_split_schedule_is_bit_identical_to_the_round3_schedule(monkeypatc
             monkeypatch.delenv(k_)
         for a, b in zip(base, got):
             assert np.array_equal(a, b), env
+
+
+def test_group_peer_copy_call_between_ranks_sharing_the_device(tmp_path):
+    """GPX_LOCAL_FORCE_PEER=1 (test hook): the in-process transport pulls with hipMemcpyPeerAsync even between ranks that
+    share a device — the call a multi-GPU group makes between DISTINCT devices and a one-GPU box otherwise never executes
+    (with equal ordinals it is an ordinary copy: same results, bit for bit).  Child process: the switch is read once."""
+    import subprocess, sys, os
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from gaussianprocesspathmodelling_amd import GP
+from oracle.gp_oracle import synthetic_problem
+X, y, Xs = synthetic_problem(3000, 3, 200, seed=3)
+out = []
+for repl in ("0", "1"):
+    import os
+    os.environ["GPX_SHARD_REPLICATE"] = repl
+    os.environ["GPX_NB_SHARD"] = "256"
+    with GP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0, devices=3, oversubscribe=True) as gp:
+        m, v = gp.fit(X, y).predict(Xs)
+        out += [m, v, gp.alpha_.copy()]
+np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for force in ("0", "1"):
+        out = str(tmp_path / f"peer{force}.npy")
+        env = dict(os.environ, GPX_LOCAL_FORCE_PEER=force)
+        r = subprocess.run([sys.executable, "-c", code, out], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    assert np.array_equal(res[0], res[1])
