@@ -88,7 +88,7 @@ static void argument_validation() {
   };
   // one field out of range at a time: 0 kernel, 1 dtype, 2 world, 3 rank, 4 ndev, 5 block, 6 refine
   for (const Bad& b : {Bad{0, 9}, Bad{1, 7}, Bad{2, 0}, Bad{2, 65}, Bad{3, 1}, Bad{3, -1}, Bad{4, -1}, Bad{4, GPX_MAX_GROUP + 1},
-                       Bad{5, 100}, Bad{5, 4096}, Bad{5, 1000}, Bad{6, -1}, Bad{6, 51}}) {
+                       Bad{5, 100}, Bad{5, 4224}, Bad{5, 1000}, Bad{6, -1}, Bad{6, 51}}) {
     gpx_config c = cfg;
     int32_t* f[] = {&c.kernel, &c.dtype, &c.world, &c.rank, &c.ndev, &c.block, &c.refine};
     *f[b.field] = b.value;
