@@ -19,6 +19,8 @@ def run(N, M, kw):
 
 out = []
 for N, M, kw, env in ((32768, 2048, {}, {}),
+                      (49152, 1024, {}, {}),          # round 4: 2048-wide panels (the library's choice from N = 40960 on)
+                      (32768, 1024, {"devices": 4, "oversubscribe": True, "dtype": "mixed"}, {"GPX_SHARD_REPLICATE": "0"}),   # round 4: mixed shard, distributed refinement
                       (16384, 1024, {"devices": 4, "oversubscribe": True}, {"GPX_SHARD_REPLICATE": "0"}),
                       (32768, 1024, {"devices": 8, "oversubscribe": True}, {"GPX_SHARD_REPLICATE": "0"})):
     os.environ.update(env)

@@ -37,7 +37,7 @@ def one_case(rng, c):
         sn2 = float(10 ** rng.uniform(-1.5, -0.5))
     bars = dict(BARS)
     if dtype == "mixed":            # fp64-grade mean and alpha; variance and log-determinant through the fp32 factor
-        bars.update(var=5e-3, logdet=1e-3)
+        bars.update(var=5e-3, logdet=1e-3, one_pass=5e-3)   # (the one-pass figure includes the variance)
     elif dtype == "float32":
         bars.update(mean=5e-3, var=5e-3, alpha=5e-2, logdet=1e-3, mean_only=5e-3, one_pass=5e-3)
     X = rng.uniform(0, 1, (N, d))
