@@ -669,7 +669,11 @@ int chol_enqueue(gpx_handle* h, T* A, int64_t ld, int64_t n, int nb, T* Winv, T*
     if (split_env) {
       hipStream_t sm = s0;
       // self-reserving main-stream products where the chain sets the pace (the criterion of the REST's early hand-over)
-      const int resv_it = (resv_k > 0 && ntrail <= (int64_t)(rest_split + 1) * nb) ? resv_k : 0;
+      static const bool resv_all = [] {  // GPX_RESV_ALL=1 (experiment): every panel's main-stream products, not only the chain-bound ones
+        const char* e = getenv("GPX_RESV_ALL");
+        return e && atoi(e) != 0;
+      }();
+      const int resv_it = (resv_k > 0 && (resv_all || ntrail <= (int64_t)(rest_split + 1) * nb)) ? resv_k : 0;
       // SPLIT STRIP (round 3, the default): of the strip only the next DIAGONAL block is on the chain.  It is
       // updated on the look-ahead stream itself, right behind the panel solve that produced its operand (no
       // hand-over between streams on the chain; 64-tiles in latency mode: a K = nb walk of a 64-tile is a
