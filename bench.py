@@ -603,6 +603,15 @@ def run(args):
                         "var_max_abs_diff_vs_two_calls": float((v1p - var).abs().max().item()),
                         "note": "gp.fit_predict(X, y, Xs): same inputs, same outputs, one factorisation pass"}
             del m1p, v1p
+    # every rank's own clocks of the timed steps (process-per-GPU shard): the JSON line carries them next to rank 0's
+    # phases, so that the first run on real GPUs can be read term by term against tools/scaling_model.py
+    per_rank = None
+    if shard and not group and world > 1:
+        mine = {k_: round(acc.get(k_, 0.0) / max(1, args.steps), 3)
+                for k_ in ("fit_total", "chol", "comm", "solve", "predict_total", "trsm")}
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        per_rank = box
     shard_check = None
     if shard and N <= 131072:
         # the sharded posterior against the single-GPU path on the same inputs (rank 0's GPU)
@@ -681,6 +690,7 @@ def run(args):
                if shard and world > 1 else {}),
             **({"fallback_from": os.environ["GPX_BENCH_FALLBACK_REASON"]} if group and os.environ.get("GPX_BENCH_FALLBACK_REASON") else {}),
             "phases_ms": phases,
+            **({"per_rank_phases_ms": per_rank} if per_rank else {}),
             "roofline": {
                 "kernel": "gemm_nt_kernel<128,LOWER> (trailing SYRK of the blocked Cholesky)",
                 "bound": "mfma", "achieved": syrk_tflops, "peak": peak_mfma,
