@@ -121,6 +121,7 @@ struct gpx_handle {
   const void* Lfac = nullptr;  // the factor the single-GPU solves read: K (unsharded) or Lfull
   // device-flag hand-overs between this handle's streams (diag_enqueue, fused strip): -1 not probed yet, 1 a kernel parked
   // on one stream sees the store of a kernel launched later on another (flag_handover_probe), 0 it does not: hipEvents
+  int64_t fq_rows = 0;  // gpx_fit_predict on a shard: padded rows of this rank's slice of the query points (bordered rows of its K buffer)
   int flag_ok = -1;
   int flag_retries = 0;  // fits of this handle that were run again with hipEvents after a parked stream timed out
   // event pool
@@ -1843,12 +1844,35 @@ int gpx_fit_predict(gpx_handle* h, const void* X, const void* y, int64_t N, int3
   for (int i = 0; i < n_ls; ++i)
     if (!(lengthscale[i] > 0.0)) return fail(h, GPX_E_ARG, "gpx_fit_predict: lengthscale must be > 0");
   if (N > (int64_t)INT_MAX - 4096) return fail(h, GPX_E_ARG, "gpx_fit_predict: N too large");
-  // Groups, shards and the mixed mode have no bordered query rows: for them the call IS the two calls (same results;
+  if (h->group) return group_fit_predict(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, Xq, M, mean, var, mem_kind, info);
+  // Shards (round 4): every rank's slice of the query points rides through the sharded factorisation as bordered rows of
+  // its local row set (shard_fit with query points + shard_fused_tail) — in the split schedule, up to 8192 rows per rank.
+  // Otherwise, and in the mixed mode (its refinement needs the factor first), the call IS the two calls (same results;
   // ABI v5 — it was GPX_E_UNSUPPORTED).  *info > 0: not positive definite, nothing predicted.
-  if (h->group || h->cfg.world > 1 || h->comm || h->cfg.dtype == GPX_MIXED) {
-    const int rc2 = gpx_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
-    if (rc2 != GPX_OK || *info != 0) return rc2;
-    return gpx_predict(h, Xq, M, mean, var, mem_kind);
+  if (h->cfg.world > 1 || h->comm || h->cfg.dtype == GPX_MIXED) {
+    const char* se = getenv("GPX_SPLIT_STRIP");
+    const char* fe = getenv("GPX_SHARD_FUSED");
+    const int P = h->comm ? h->comm->world : 1;
+    const bool ride = h->comm && h->cfg.dtype != GPX_MIXED && (!se || atoi(se) != 0) && (!fe || atoi(fe) != 0) &&
+                      round_up((M + P - 1) / P, TILE) <= 8192;
+    if (!ride) {
+      const int rc2 = gpx_fit(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info);
+      if (rc2 != GPX_OK || *info != 0) return rc2;
+      return gpx_predict(h, Xq, M, mean, var, mem_kind);
+    }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    h->fitted = false;
+    h->err.clear();
+    h->phases.clear();
+    h->ev_used = 0;
+    int rc2 = h->cfg.dtype == GPX_F32
+                  ? shard_fit<float>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info, false, Xq, M)
+                  : shard_fit<double>(h, X, y, N, d, k, lengthscale, n_ls, sf2, sn2, jitter, mem_kind, info, false, Xq, M);
+    if (rc2 != GPX_OK || !h->fitted) return rc2;
+    h->phases.clear();
+    h->ev_used = 0;
+    return h->cfg.dtype == GPX_F32 ? shard_fused_tail<float>(h, M, mean, var, mem_kind)
+                                   : shard_fused_tail<double>(h, M, mean, var, mem_kind);
   }
   // one batch of query points rides through the factorisation; more than that (ABI v5: it was GPX_E_UNSUPPORTED): the
   // first batch rides, the others go through the ordinary predict against the factor the pass leaves behind — query

@@ -254,8 +254,9 @@ class GP:
         of the query points ride through the blocked Cholesky as bordered rows (``gpx_fit_predict``), so the
         variance solve is part of the trailing updates instead of a pass of its own — the small-N schedule
         (N = 8192: the updates' idle CUs take the work).  The model is fitted afterwards as after ``fit``.
-        Groups, shards, ``dtype="mixed"`` and more query points than one predict batch take the two calls."""
-        fused = not self._is_group and not self._has_comm and self.dtype in ("float64", "float32")
+        On a shard or a device group every rank's slice of the query points rides through ITS part of the sharded
+        factorisation (collective: every rank of a shard makes the call).  ``dtype="mixed"`` takes the two calls."""
+        fused = self.dtype in ("float64", "float32")
         pq, kq, keepq, devq, sq = self._as_input(Xs, "Xs")
         px, kx, keepx, devx, sx = self._as_input(X, "X")
         py, ky, keepy, devy, sy = self._as_input(y, "y")

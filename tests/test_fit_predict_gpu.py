@@ -141,9 +141,9 @@ def test_fit_predict_jitter_escalation_many_query_points_and_buffer_reuse():
 @pytest.mark.parametrize("kw", [{"devices": 3, "oversubscribe": True}, {"dtype": "mixed"},
                                 {"device": 0, "world": 1, "rank": 0, "comm": "rccl"}])
 def test_c_abi_fit_predict_on_groups_shards_and_mixed_handles(kw):
-    """ABI v5: gpx_fit_predict is accepted by EVERY handle (v4: GPX_E_UNSUPPORTED on groups, shards, mixed) — there it
-    runs as gpx_fit + gpx_predict, same results.  Called through the C ABI directly (GP.fit_predict makes the two calls
-    itself for these handles)."""
+    """ABI v5: gpx_fit_predict is accepted by EVERY handle (v4: GPX_E_UNSUPPORTED on groups, shards, mixed).  Mixed: it
+    runs as gpx_fit + gpx_predict, same bits.  Groups and shards: the query rows ride through the sharded factorisation
+    (tests/test_group_gpu.py), equal to the two calls at 1e-9.  Called through the C ABI directly."""
     import ctypes as C
     from gaussianprocesspathmodelling_amd import _abi
     X, y, Xs = synthetic_problem(2000, 3, 150, seed=17)
@@ -155,4 +155,7 @@ def test_c_abi_fit_predict_on_groups_shards_and_mixed_handles(kw):
                                      1.5, 1e-2, 0.0, Xs.ctypes.data_as(C.c_void_p), 150, mean.ctypes.data_as(C.c_void_p),
                                      var.ctypes.data_as(C.c_void_p), _abi.MEM_HOST, C.byref(info))
         assert rc == 0 and info.value == 0
-        assert np.array_equal(mean, m2) and np.array_equal(var, v2)
+        if kw.get("dtype") == "mixed":
+            assert np.array_equal(mean, m2) and np.array_equal(var, v2)
+        else:
+            assert np.max(np.abs(mean - m2)) <= 1e-9 * np.abs(m2).max() and np.max(np.abs(var - v2)) <= 1e-9 * 1.5

@@ -377,3 +377,81 @@ np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(np.load(out))
     assert np.array_equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("ndev,kernel,nb,N,M,repl,k,dtype", [
+    (2, "rbf", 128, 700, 90, 0, 1, "float64"), (2, "rbf", 128, 700, 90, 1, 1, "float64"),
+    (3, "matern52", 128, 1500, 500, 0, 2, "float64"), (4, "rbf", 512, 3300, 130, 1, 1, "float64"),
+    (8, "matern52", 128, 2000, 77, 0, 1, "float64"), (8, "rbf", 256, 5000, 1300, 1, 3, "float64"),
+    (2, "rbf", 128, 100, 5, 0, 1, "float64"),       # one block: rank 1 owns no rows, only its query slice
+    (5, "rbf", 128, 250, 3, 1, 1, "float64"),       # fewer query points than ranks: four ranks ride nothing
+    (2, "rbf", 0, 9000, 4096, -1, 1, "float64"),    # block height / mode chosen by the library
+    (4, "matern52", 256, 4000, 600, 0, 1, "float32"), (3, "rbf", 256, 4000, 600, 1, 1, "float32"),
+])
+def test_group_fit_predict_rides_the_query_rows_through_the_sharded_factorisation(monkeypatch, ndev, kernel, nb, N, M, repl, k, dtype):
+    """``GP.fit_predict`` on a device group (round 4): every rank's slice of the query points rides through ITS part of
+    the sharded factorisation as bordered rows (shard_fit with query points; gpx_fit_predict on the member handles).
+    Against the oracle at the elementwise bar of the two calls, against the two calls on the same group at 1e-9 (fp64; the
+    sums run in another order), the model left behind equal to a plain fit's, and a refit in the grown buffers."""
+    if nb:
+        monkeypatch.setenv("GPX_NB_SHARD", str(nb))
+    else:
+        monkeypatch.delenv("GPX_NB_SHARD", raising=False)
+    if repl >= 0:
+        monkeypatch.setenv("GPX_SHARD_REPLICATE", str(repl))
+    X, Y, Xs = synthetic_problem(N, 3, M, seed=N + M)
+    if k > 1:
+        Y = np.stack([Y * (j + 1) + 0.1 * j * np.cos(5.0 * X[:, 0]) for j in range(k)], axis=1)
+    ls = (0.3, 0.2, 0.25)
+    ref = OracleGP(kernel, ls, 1.5, 1e-2, jitter=0.0).fit(X, Y)
+    mr, vr = ref.predict(Xs)
+    f32 = dtype == "float32"
+    Xc, Yc, Xsc = (a.astype(np.float32) for a in (X, Y, Xs)) if f32 else (X, Y, Xs)
+    with GP(kernel, ls, 1.5, 1e-2, jitter=0.0, devices=ndev, oversubscribe=True, dtype=dtype) as gp:
+        mean, var = gp.fit_predict(Xc, Yc, Xsc)
+        a1, l1 = gp.alpha_.copy(), gp.log_det_
+        if f32:
+            assert np.max(np.abs(mean - mr)) <= 2e-2 * np.abs(mr).max() and np.max(np.abs(var - vr)) <= 5e-2 * 1.5
+        elif k > 1:
+            assert np.max(np.abs(mean - mr)) <= 1e-8 * np.abs(mr).max() and np.max(np.abs(var - vr) / np.maximum(vr, 1.5e-6)) <= 1e-6
+        else:
+            check(mean, var, a1, l1, ref, mr, vr)
+        m2, v2 = gp.fit(Xc, Yc).predict(Xsc)
+        assert np.array_equal(gp.alpha_, a1) and gp.log_det_ == l1       # the factorisation itself: not a bit changes
+        bar = 2e-3 if f32 else 1e-9
+        assert np.max(np.abs(mean - m2)) <= bar * max(1.0, np.abs(m2).max())
+        assert np.max(np.abs(var - v2)) <= bar * 1.5
+        m3, v3 = gp.fit_predict(Xc, Yc, Xsc)                             # again, buffers and events reused
+        assert np.array_equal(m3, mean) and np.array_equal(v3, var)
+        m4, v4 = gp.predict(Xsc)                                         # the model it leaves behind predicts as a fit's
+        assert np.array_equal(m4, m2) and np.array_equal(v4, v2)
+
+
+def test_group_fit_predict_reports_a_bad_pivot_and_honours_the_switches(monkeypatch):
+    X, y, Xs = synthetic_problem(1500, 3, 200, seed=5)
+    Xd = np.vstack([X[:700], X[:700], X[700:800]])                      # duplicate rows, no noise: not positive definite
+    with GP("rbf", 0.3, 1.5, 0.0, jitter=0.0, devices=3, oversubscribe=True, max_tries=1) as gp:
+        with pytest.raises(np.linalg.LinAlgError):
+            gp.fit_predict(Xd, y, Xs)
+    monkeypatch.setenv("GPX_NB_SHARD", "128")
+    with GP("rbf", 0.3, 1.5, 1e-2, jitter=0.0, devices=3, oversubscribe=True) as gp:
+        base = gp.fit_predict(X, y, Xs)
+        for env in ({"GPX_SHARD_FUSED": "0"}, {"GPX_SPLIT_STRIP": "0"}):  # both: the two calls inside the library
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            two = gp.fit_predict(X, y, Xs)
+            ref2 = gp.predict(Xs)
+            for k_ in env:
+                monkeypatch.delenv(k_)
+            assert np.array_equal(two[0], ref2[0]) and np.array_equal(two[1], ref2[1])
+            assert np.max(np.abs(two[0] - base[0])) <= 1e-9 and np.max(np.abs(two[1] - base[1])) <= 1e-9
+        for env in ({"GPX_REST_SPLIT": "0"}, {"GPX_REST_SPLIT": "1000"}, {"GPX_SHARD_DENSE_PANEL": "0"}):
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            got = gp.fit_predict(X, y, Xs)
+            for k_ in env:
+                monkeypatch.delenv(k_)
+            if "GPX_REST_SPLIT" in env:                                   # the same arithmetic in the same order
+                assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
+            else:
+                assert np.max(np.abs(got[0] - base[0])) <= 1e-8 and np.max(np.abs(got[1] - base[1])) <= 1e-8
