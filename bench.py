@@ -307,6 +307,9 @@ def main():
                          "bounded live sample; full: live without the memory check; record / sample: see cpu_baseline()")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="= --cpu-baseline full (kept from round 3)")
     ap.add_argument("--no-microbench", action="store_true")
+    ap.add_argument("--one-pass", action="store_true",
+                    help="process-per-GPU shard, several ranks: also time gp.fit_predict (collective; one rank, groups and the "
+                         "unsharded handle always do)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # Bare launch (`python bench.py --gpus N`, no launcher): start the one-process-per-GPU launcher ourselves,
@@ -612,6 +615,39 @@ def run(args):
         box = [None] * world
         dist.all_gather_object(box, mine)
         per_rank = box
+    # the ONE-PASS form on the sharded schedule (round 4: every rank's slice of the query points rides through its part of
+    # the factorisation): beside the headline, never `value`.  One rank and groups (one process makes the calls: an error
+    # is an exception here and every rank still reaches the barrier); process-per-GPU shards of several ranks on request.
+    if shard and dtype in ("float64", "float32") and ok and (world == 1 or group or args.one_pass):
+        err1 = None
+        m1p = v1p = None
+        try:
+            if gp is not None:
+                gp.fit_predict(Xd, yd, Xsd)
+        except Exception as e:  # noqa: BLE001 — the headline above is complete without it
+            err1 = f"{type(e).__name__}: {e}"[:300]
+        sync()                                   # every rank reaches every barrier, whatever happened on rank 0
+        t1 = time.perf_counter()
+        try:
+            if gp is not None and err1 is None:
+                m1p, v1p = gp.fit_predict(Xd, yd, Xsd)
+        except Exception as e:  # noqa: BLE001
+            err1 = f"{type(e).__name__}: {e}"[:300]
+        sync()
+        ms1 = (time.perf_counter() - t1) * 1e3
+        if world > 1:
+            t = torch.tensor([ms1], dtype=torch.float64, device=dev if ctrl_nccl else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms1 = float(t.item())
+        if err1 is not None:
+            one_pass = {"error": err1}
+        elif gp is not None:
+            one_pass = {"ms_per_step": ms1, "points_per_s": (N + M) / (ms1 * 1e-3),
+                        "mean_max_abs_diff_vs_two_calls": float((m1p - mean).abs().max().item()),
+                        "var_max_abs_diff_vs_two_calls": float((v1p - var).abs().max().item()),
+                        "note": "gp.fit_predict(X, y, Xs) on the shard: one timed call after one warm-up call"}
+        del m1p, v1p
+        beat(args, "one pass")
     shard_check = None
     if shard and N <= 131072:
         # the sharded posterior against the single-GPU path on the same inputs (rank 0's GPU)

@@ -78,6 +78,26 @@ def test_one_pass_fit_predict_does_not_depend_on_stream_timing(delay):
             assert np.array_equal(gp.alpha_, a0) and gp.log_det_ == ld0, f"seed {seed}"
 
 
+@pytest.mark.parametrize("ndev,repl", [(3, 0), (4, 1), (8, 0)])
+def test_group_one_pass_does_not_depend_on_stream_timing(monkeypatch, delay, ndev, repl):
+    """The same on a device group (round 4): every rank's slice of the query points as bordered rows of the SHARDED
+    factorisation — their panel solves share the panel buffers, the copy-back stream and the events of the own rows, and the
+    last panel now has an exchange of its own.  256-blocks, delays in front of a third of all launches and exchanges, five
+    seeds: bit-identical."""
+    monkeypatch.setenv("GPX_NB_SHARD", "256")
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", str(repl))
+    X, y, Xs = synthetic_problem(4000, 3, 700, seed=78)
+    with GP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0, devices=ndev, oversubscribe=True) as gp:
+        base = gp.fit_predict(X, y, Xs)
+        a0, ld0 = gp.alpha_.copy(), gp.log_det_
+        for seed in (1, 7, 123456789, 2024, 99):
+            delay(seed)
+            mean, var = gp.fit_predict(X, y, Xs)
+            delay(0)
+            assert np.array_equal(mean, base[0]) and np.array_equal(var, base[1]), f"seed {seed}"
+            assert np.array_equal(gp.alpha_, a0) and gp.log_det_ == ld0, f"seed {seed}"
+
+
 def run_delay_case(monkeypatch, delay, N, M, kw, grad, small):
     if small:
         monkeypatch.setenv("GPX_NB_SHARD", "256")

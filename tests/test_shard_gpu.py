@@ -79,6 +79,33 @@ def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N, repl):
     assert np.array_equal(res[0]["mean"], res[-1]["mean"]) and np.array_equal(res[0]["var"], res[-1]["var"])
 
 
+@pytest.mark.parametrize("world,kernel,nb,N,M,repl,dtype", [
+    (2, "rbf", 128, 700, 90, 0, "float64"), (3, "matern52", 128, 700, 300, 1, "float64"), (4, "rbf", 512, 3300, 1000, 0, "float64"),
+    (2, "rbf", 128, 100, 5, 0, "float64"), (3, "rbf", 128, 250, 2, 1, "float64"), (2, "rbf", 0, 9000, 600, -1, "float64"),
+    (3, "rbf", 256, 2000, 400, 0, "float32")])
+def test_one_pass_fit_predict_over_the_host_transport(tmp_path, world, kernel, nb, N, M, repl, dtype):
+    """Round 4: ``GP.fit_predict`` on a process-per-rank shard — every rank's slice of the query points rides through ITS
+    part of the factorisation as bordered rows (collective decisions depend on M alone: ranks with an empty slice make the
+    same broadcasts).  Oracle bar of the two calls; equal to the two calls on the factor it leaves behind at 1e-9 (fp64)."""
+    env = {"SHARD_KERNEL": kernel, "SHARD_NB": str(nb), "SHARD_N": str(N), "SHARD_M": str(M), "SHARD_ONE_PASS": "1",
+           "SHARD_DTYPE": dtype}
+    if repl >= 0:
+        env["GPX_SHARD_REPLICATE"] = str(repl)
+    res = run_ranks("gpu", world, tmp_path, env, timeout=600)
+    X, y, Xs = synthetic_problem(N, 3, M, seed=77)
+    ref = OracleGP(kernel, (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    for r in res:
+        assert int(r["info"]) == 0
+        if dtype == "float64":
+            check(r["mean"], r["var"], r["alpha"], float(r["logdet"]), ref, mr, vr)
+            assert np.max(np.abs(r["mean"] - r["mean_two_calls"])) <= 1e-9 * max(1.0, np.abs(mr).max())
+            assert np.max(np.abs(r["var"] - r["var_two_calls"])) <= 1e-9 * 1.5
+        else:
+            assert np.max(np.abs(r["mean"] - mr)) <= 2e-3 * np.abs(mr).max() and np.max(np.abs(r["var"] - vr)) <= 2e-3 * 1.5
+    assert np.array_equal(res[0]["mean"], res[-1]["mean"]) and np.array_equal(res[0]["var"], res[-1]["var"])
+
+
 @pytest.mark.parametrize("world,dtype,nb,N,repl", [(2, "float32", 128, 700, 0), (3, "float32", 256, 2000, 1),
                                                    (2, "mixed", 128, 1500, 0), (3, "mixed", 256, 2000, 1)])
 def test_fp32_and_mixed_shards_over_the_host_transport(tmp_path, world, dtype, nb, N, repl):
