@@ -142,11 +142,15 @@ int gpx_predict(gpx_handle* h, const void* Xs, int64_t M, void* mean, void* var,
  * rows of the trailing updates (at small N they run on the CUs the serial diagonal chain leaves idle; N = 8192,
  * M = 4096: 12.6 -> 11.5 ms per step).  Same results as the two calls up to the rounding of a different
  * summation order; the handle is fitted afterwards exactly as after gpx_fit (gpx_predict, gpx_get_alpha,
- * gpx_lml_grad ... work on it).  *info > 0: not positive definite, nothing was predicted.  The query rows ride on
- * single-device GPX_F64 / GPX_F32 handles, one predict batch (8192 rows) of them; ABI v5: further batches go through the
- * ordinary predict against the factor the pass leaves behind, and groups, shards and GPX_MIXED handles run the call as
- * gpx_fit + gpx_predict — every handle accepts it (v4: GPX_E_UNSUPPORTED), with the same results.  Mirrors the
- * reference-side usage `gp.fit(X, y); gp.predict(Xs)`. */
+ * gpx_lml_grad ... work on it).  *info > 0: not positive definite, nothing was predicted.  ABI v5: every handle
+ * accepts the call (v4: GPX_E_UNSUPPORTED beyond single-device fp64 / fp32 handles and one batch).  Single device,
+ * GPX_F64 / GPX_F32: one predict batch (8192 rows) rides, further batches go through the ordinary predict against the
+ * factor the pass leaves behind.  Shards and device groups (GPX_F64 / GPX_F32): rank r's slice of the query points —
+ * ceil(M / world) rounded up to 128 — rides through ITS part of the sharded factorisation as bordered rows of its local
+ * row set (up to 8192 rows per rank; a collective call: every rank of a shard makes it with the same arguments), in
+ * both solve modes; GPX_SHARD_FUSED=0 runs the two calls instead.  GPX_MIXED handles run the call as gpx_fit +
+ * gpx_predict (the refinement needs the factor first).  Mirrors the reference-side usage `gp.fit(X, y);
+ * gp.predict(Xs)`. */
 int gpx_fit_predict(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d, int32_t k,
                     const double* lengthscale, int32_t n_ls, double sf2, double sn2, double jitter, const void* Xs,
                     int64_t M, void* mean, void* var /* may be NULL */, int32_t mem_kind, int64_t* info);

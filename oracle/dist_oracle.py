@@ -49,7 +49,12 @@ def _lb0(p, r, P):
     return (p - r) // P + 1 if p >= r else 0
 
 
-def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb):
+def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb, one_pass=False):
+    """one_pass (gpx_fit_predict on a shard, gpx_shard.inc shard_fit with query points + shard_fused_tail): rank r's slice
+    of the query points — Mc = ceil(M / P) rounded up to 128 per rank — rides through the factorisation as bordered rows
+    B = K(Xs_r, X): every panel (the LAST one too: one more broadcast) solves them with the diagonal block and updates all
+    their remaining columns; they end as V_r^T.  mean_r = V_r^T z with z = L^-1 y replicated, var_r = sf2 - row norms;
+    one all-gather of the slices."""
     P, r = coll.world, coll.rank
     N, M = len(X), len(Xs)
     Npad = -(-N // nb) * nb
@@ -68,6 +73,11 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb):
         blk[:, N:] = 0.0
         blk[np.arange(nb), gi] += np.where(gi < N, sn2, 1.0)
         A[lb * nb:(lb + 1) * nb] = blk
+    if one_pass:
+        Mc = -(-(-(-M // P)) // 128) * 128
+        q0, q1 = min(M, r * Mc), min(M, (r + 1) * Mc)
+        B = kernel_matrix(Xs[q0:q1], Xp, kernel, ls, sf2) if q1 > q0 else np.zeros((0, Npad))
+        B[:, N:] = 0.0
     logdet = np.zeros(1)
     for p in range(nblk):
         o, root, lo = p * nb, p % P, (p // P) * nb
@@ -76,9 +86,13 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb):
             D[:] = cholesky(A[lo:lo + nb, o:o + nb], lower=True)
             A[lo:lo + nb, o:o + nb] = D
             logdet += 2.0 * np.sum(np.log(np.diag(D)))
-        if p + 1 == nblk:
+        if p + 1 == nblk and not one_pass:
             break
         coll.bcast(D, root)
+        if one_pass:  # (a collective decision: every rank takes the last block too, also with an empty slice)
+            B[:, o:o + nb] = solve_triangular(D, B[:, o:o + nb].T, lower=True).T
+        if p + 1 == nblk:
+            break
         l0 = _lb0(p, r, P)
         rows = nloc - l0 * nb
         if rows > 0:
@@ -97,6 +111,8 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb):
             g = own[lb]
             cols = slice((p + 1) * nb, (g + 1) * nb)
             A[lb * nb:(lb + 1) * nb, cols] -= A[lb * nb:(lb + 1) * nb, o:o + nb] @ Pg[:(g - p) * nb].T
+        if one_pass:  # the bordered rows: blocks beyond the matrix, every remaining column
+            B[:, (p + 1) * nb:] -= B[:, o:o + nb] @ Pg.T
     coll.allreduce_sum(logdet)
 
     def local(v):  # (Npad, k) -> local rows
@@ -117,6 +133,11 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb):
         l0 = _lb0(p, r, P)
         if nloc - l0 * nb > 0:
             z[l0 * nb:] -= A[l0 * nb:nloc, o:o + nb] @ S
+    if one_pass:
+        z_full = np.zeros((Npad, 1))
+        for lb, g in enumerate(own):
+            z_full[g * nb:(g + 1) * nb] = z[lb * nb:(lb + 1) * nb]
+        coll.allreduce_sum(z_full)
     cneg = np.zeros((Npad, 1))
     for p in range(nblk - 1, -1, -1):          # backward: reduce the partial products
         o, root, lo = p * nb, p % P, (p // P) * nb
@@ -132,6 +153,16 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb):
         alpha_full[g * nb:(g + 1) * nb] = z[lb * nb:(lb + 1) * nb]
     coll.allreduce_sum(alpha_full)
 
+    if one_pass:
+        send = np.zeros((Mc, 2))
+        send[:q1 - q0, 0] = (B @ z_full)[:, 0]
+        send[:q1 - q0, 1] = sf2 - np.einsum("ij,ij->i", B, B)
+        parts = coll.allgather(send)
+        mean, var = np.zeros(M), np.zeros(M)
+        for rr in range(P):
+            a0, a1 = min(M, rr * Mc), min(M, (rr + 1) * Mc)
+            mean[a0:a1], var[a0:a1] = parts[rr][:a1 - a0, 0], parts[rr][:a1 - a0, 1]
+        return mean, var, alpha_full[:N, 0], float(logdet[0])
     Ks = np.zeros((M, max(nloc, 0)))
     for lb, g in enumerate(own):
         blk = kernel_matrix(Xs, Xp[g * nb:(g + 1) * nb], kernel, ls, sf2)

@@ -3,6 +3,8 @@ this ordinary pytest process: no launcher, no torch.distributed.  The developmen
 GPU, so the ranks share it (``oversubscribe`` / a repeated ordinal) over the LOCAL transport:
 peer copies and hipEvents between the ranks' streams, i.e. for the first time the look-ahead
 stream's exchanges really run concurrently with the main stream's trailing update."""
+import time
+
 import numpy as np
 import pytest
 
@@ -309,11 +311,20 @@ def test_c4_real_shape_world8_nb1024_n131072():
         with GP(jitter=0.0, devices=[0] * 8, **C4) as gp:
             r = c4_run(gp, N, M)
             tm = gp.timings_
+            # the same step as ONE pass (round 4: 128 query rows per rank ride through the sharded factorisation)
+            from oracle.gp_oracle import synthetic_problem as sp
+            X, y, Xs = sp(N, 3, M, seed=12345)
+            t0 = time.perf_counter()
+            m1p, v1p = gp.fit_predict(X, y, Xs)
+            t_one = (time.perf_counter() - t0) * 1e3
+            assert np.array_equal(gp.alpha_, r["alpha"]) and gp.log_det_ == r["logdet"]
+            assert np.max(np.abs(m1p - r["mean"])) <= 1e-9 * np.abs(r["mean"]).max()
+            assert np.max(np.abs(v1p - r["var"])) <= 1e-9 * 1.5
     finally:
         os.environ.pop("GPX_SHARD_REPLICATE", None)
     resid = c4_checks([r], N, M, single_gpu_c4(N, M))
     print(f"C4 real shape (P = 8 x nb = 1024), N={N} on one card: residual {resid:.2e}, fit {tm['fit_total']:.0f} ms "
-          f"(chol {tm['chol']:.0f} ms, comm {tm['comm']:.0f} ms), predict {tm['predict_total']:.0f} ms")
+          f"(chol {tm['chol']:.0f} ms, comm {tm['comm']:.0f} ms), predict {tm['predict_total']:.0f} ms; one pass incl. host copies {t_one:.0f} ms")
 
 
 @pytest.mark.parametrize("ndev,N,nb,repl", [(3, 4000, 256, 0), (4, 4000, 256, 1), (2, 9000, 0, 1), (8, 6000, 128, 0)])

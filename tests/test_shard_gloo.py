@@ -30,10 +30,14 @@ def test_host_collective_callbacks_world2(tmp_path):
     assert np.array_equal(res[1]["reduce"], np.full(6, -1.0))            # non-root untouched
 
 
-@pytest.mark.parametrize("world,kernel", [(2, "rbf"), (3, "matern52")])
-def test_sharded_schedule_matches_oracle(tmp_path, world, kernel):
-    res = run_ranks("oracle", world, tmp_path, {"SHARD_KERNEL": kernel, "SHARD_NB": "128"})
-    X, y, Xs = synthetic_problem(700, 3, 90, seed=77)
+@pytest.mark.parametrize("world,kernel,one_pass,M", [(2, "rbf", 0, 90), (3, "matern52", 0, 90),
+                                                     (2, "rbf", 1, 90),        # one pass: rank 1's slice is empty
+                                                     (3, "matern52", 1, 300)])
+def test_sharded_schedule_matches_oracle(tmp_path, world, kernel, one_pass, M):
+    """one_pass: the query points as bordered rows of the sharded factorisation (gpx_fit_predict on a shard)."""
+    res = run_ranks("oracle", world, tmp_path, {"SHARD_KERNEL": kernel, "SHARD_NB": "128", "SHARD_ONE_PASS": str(one_pass),
+                                                "SHARD_M": str(M)})
+    X, y, Xs = synthetic_problem(700, 3, M, seed=77)
     ref = OracleGP(kernel, (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
     mr, vr = ref.predict(Xs)
     for r in res:
