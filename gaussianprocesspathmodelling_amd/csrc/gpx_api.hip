@@ -113,7 +113,7 @@ struct gpx_handle {
   int nb_shard = 512;  // distribution block = panel width of the sharded factorisation (chosen per fit)
   int nb_shard_env = 0;  // GPX_NB_SHARD override (0: choose from N and the number of ranks)
   int64_t nloc = 0, ldy = 0;
-  DevBuf G, Pglob, Dbuf, Sbuf, YTloc, Cneg, Sv;
+  DevBuf G, Dbuf, Sbuf, YTloc, Cneg, Sv;
   // replicated-factor mode of the shard: every rank keeps the whole L (the panels pass through
   // it anyway), so solves and predictions need no per-panel exchange (gpx_shard.inc)
   bool repl = false;
@@ -1781,7 +1781,7 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st3) (void)hipStreamSynchronize(h->st3);
   if (h->st4) (void)hipStreamSynchronize(h->st4);
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
-                    &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->MTpart, &h->var, &h->meanout, &h->G, &h->Pglob,
+                    &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->MTpart, &h->var, &h->meanout, &h->G,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
                     &h->GatherR, &h->outM, &h->outV, &h->ZT, &h->ZTloc, &h->ZTpack, &h->gpart, &h->Wblk, &h->Ublk, &h->Tsol, &h->X64, &h->Y64, &h->Xs64,
                     &h->A64, &h->Aprev, &h->R64, &h->resv_ring, &h->RTloc, &h->P32out, &h->X32, &h->Y32, &h->RT32, &h->Q64, &h->Qs64, &h->Q32, &h->M64, &h->rn, &h->Zfew})

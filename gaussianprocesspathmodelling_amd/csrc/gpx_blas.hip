@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, (BT == 64 && KSUB >= 4) ? 1 : 2) void gemm_nt_
     r0 = __builtin_amdgcn_s_memrealtime();
   }
 #endif
-  gemm_tile_g<T, BT, BT, 2, KSUB>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc,
+  gemm_tile_g<T, BT, BT, 2, KSUB>(A + (int64_t)ti * BT * lda, lda, B + bc_brow<BT>(bc, tj) * ldb, ldb, K, acc,
                                   smem);
 #ifdef GPX_STAMPS
   long long cL = 0;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_stair_kernel(
   if (ti >= tiles_m || tj >= tiles_n) return;  // ragged bottom edge only
   typename Num<T>::v4 acc[BT / 32][BT / 32];
   zero_acc(acc);
-  gemm_tile_g<T, BT, BT>(A + (int64_t)ti * BT * lda, lda, B + (int64_t)tj * BT * ldb, ldb, K, acc,
+  gemm_tile_g<T, BT, BT>(A + (int64_t)ti * BT * lda, lda, B + bc_brow<BT>(bc, tj) * ldb, ldb, K, acc,
                          smem);
   store_tile<T, BT, BT, MODE>(C + (int64_t)ti * BT * ldc + (int64_t)tj * BT, ldc, acc);
 }
@@ -1344,10 +1344,14 @@ unsigned launch_gemm_nt_fused(T* C, int64_t ldc, const T* P, int64_t ldp, int64_
 
 template <typename T>
 void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
-                       int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c, hipStream_t st) {
+                       int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c, hipStream_t st, int g0, int p,
+                       int64_t piece) {
   debug_delay(st);
   if (m <= 0 || n <= 0) return;
-  const BcMask bc{bc_P, bc_tpb, bc_c};
+  BcMask bc{bc_P, bc_tpb, bc_c};
+  bc.g0 = g0;  // piece > 0: B is the all-gathered panel in rank-major order (bc_brow)
+  bc.p = p;
+  bc.piece = piece;
   const int64_t tm = m / 128, tn = n / 128;
   const int64_t nsr = (tm + 7) / 8;
   if (nsr > STAIR_MAX) {  // beyond the by-value map: bounding rectangle with the mask
@@ -1447,7 +1451,7 @@ extern "C" int gpx_debug_read_syrk_clock(long long* out) {
   template unsigned launch_gemm_nt_fused<T>(T*, int64_t, const T*, int64_t, int64_t, int64_t, int64_t,  \
                                             unsigned*, hipStream_t);                                    \
   template void launch_gemm_nt_bc<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,        \
-                                     int64_t, int64_t, int, int, int, hipStream_t);                     \
+                                     int64_t, int64_t, int, int, int, hipStream_t, int, int, int64_t);  \
   template void launch_gemm_nn<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t, int64_t,  \
                                   int64_t, hipStream_t);                                                \
   template void launch_gemm_nt_splitk<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,    \

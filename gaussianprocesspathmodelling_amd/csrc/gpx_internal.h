@@ -131,7 +131,8 @@ void launch_gemm_nt_splitk(T* C, int64_t ldc, const T* A, int64_t lda, const T* 
                            int64_t n, int64_t k, int S, T* part, int64_t ldp, hipStream_t st);
 template <typename T>
 void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
-                       int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c, hipStream_t st);
+                       int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c, hipStream_t st, int g0 = 0, int p = 0,
+                       int64_t piece = 0);  // piece > 0: B = the all-gathered panel p in rank-major pieces, tile column 0 = block g0
 // C (m x n, ldc) -= A (m x k, lda) * B (k x n, ldb); 64x64 tiles.
 template <typename T>
 void launch_gemm_nn(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
@@ -222,9 +223,10 @@ void launch_path_distance(const double* paths, int64_t P, const double* cents, i
 template <typename T>
 void launch_fix_diag(T* A, int64_t lda, int n, int nvalid, double add, hipStream_t st);
 // Gathered panel G [P][maxcnt][ldp] (rank-major, each rank's trailing rows in local order)
-// -> Pglob [(nblk-p-1)*nb][ldp] in global row order.
+// -> dst [(nblk-p-1)*nb][ldd] in global row order (the replicated factor's column block p: the update kernels read
+// the gathered panel in place, bc_brow in gpx_tile.h).
 template <typename T>
-void launch_unpermute_panel(const T* G, T* Pglob, int64_t ldp, int nb, int P, int p, int nblk, int64_t maxcnt,
+void launch_unpermute_panel(const T* G, int64_t ldp, T* dst, int64_t ldd, int nb, int P, int p, int nblk, int64_t maxcnt,
                             hipStream_t st);
 // YTloc[r][lb*nb + i] = y[(g*nb+i)*k + r] for the blocks g = rank + lb*P owned by `rank`.
 template <typename T>

@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void fix_diag_kernel(T* A, int64_t lda, int n,
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void unpermute_panel_kernel(const T* __restrict__ G, T* __restrict__ Pglob, int64_t ldp,
-                                                             int nb, int P, int p, int64_t maxcnt) {
+__global__ __launch_bounds__(256) void unpermute_panel_kernel(const T* __restrict__ G, int64_t ldp, T* __restrict__ Pglob,
+                                                             int64_t ldd, int nb, int P, int p, int64_t maxcnt) {
   // blockIdx.y = trailing block b (global block g = p+1+b), blockIdx.x strides rows of the block
   typedef float v4 __attribute__((ext_vector_type(4)));  // 16-byte pieces whatever the element type
   constexpr int E = 16 / (int)sizeof(T);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void unpermute_panel_kernel(const T* __restric
        e += (int64_t)gridDim.x * 256) {
     const int64_t row = e / c2;
     const int col = (int)(e - row * c2) * E;
-    *reinterpret_cast<v4*>(Pglob + (dst_row0 + row) * ldp + col) =
+    *reinterpret_cast<v4*>(Pglob + (dst_row0 + row) * ldd + col) =
         *reinterpret_cast<const v4*>(G + (src_row0 + row) * ldp + col);
   }
 }
@@ -247,11 +247,11 @@ void launch_fix_diag(T* A, int64_t lda, int n, int nvalid, double add, hipStream
 }
 
 template <typename T>
-void launch_unpermute_panel(const T* G, T* Pglob, int64_t ldp, int nb, int P, int p, int nblk, int64_t maxcnt,
+void launch_unpermute_panel(const T* G, int64_t ldp, T* dst, int64_t ldd, int nb, int P, int p, int nblk, int64_t maxcnt,
                             hipStream_t st) {
   const int ntb = nblk - p - 1;
   if (ntb <= 0) return;
-  hipLaunchKernelGGL(unpermute_panel_kernel<T>, dim3(64, (unsigned)ntb), dim3(256), 0, st, G, Pglob, ldp, nb, P, p, maxcnt);
+  hipLaunchKernelGGL(unpermute_panel_kernel<T>, dim3(64, (unsigned)ntb), dim3(256), 0, st, G, ldp, dst, ldd, nb, P, p, maxcnt);
 }
 
 template <typename T>
@@ -426,7 +426,7 @@ void launch_logdet(const T* A, int64_t lda, int64_t n, double* out, hipStream_t 
   template void launch_set_diag_one_t<T>(T*, int64_t, int64_t, hipStream_t);                        \
   template void launch_copy2d<T>(T*, int64_t, const T*, int64_t, int64_t, int64_t, hipStream_t);           \
   template void launch_fix_diag<T>(T*, int64_t, int, int, double, hipStream_t);                           \
-  template void launch_unpermute_panel<T>(const T*, T*, int64_t, int, int, int, int, int64_t, hipStream_t); \
+  template void launch_unpermute_panel<T>(const T*, int64_t, T*, int64_t, int, int, int, int, int64_t, hipStream_t); \
   template void launch_pack_rhs_local<T>(const T*, int64_t, int, T*, int64_t, int, int, int, int, int, hipStream_t); \
   template void launch_scatter_local<T>(const T*, int64_t, T*, int64_t, int, int, int, int, int, hipStream_t); \
   template void launch_add_block<T>(T*, int64_t, const T*, int64_t, int, int, double, hipStream_t);        \
