@@ -9,8 +9,10 @@ exists, the per-term deviations point at the cause.
 Schedule modelled (csrc/gpx_shard.inc, round 4): row blocks of height nb dealt block-cyclically; per panel p
   main stream      : STRIP_B(p) (own rows below block p+1, its columns) -> REST(p)          (own rows; MFMA-bound)
   look-ahead stream: STRIP_D(p) (the next diagonal block only, on its owner) -> diagonal block p+1 -> broadcast
-                     [L_pp | inverses | W_p] -> every rank solves its rows of panel p+1 -> all-gather -> un-permute
-  step time        = max(STRIP_B(p) + REST(p), chain(p+1))
+                     [L_pp | inverses | W_p] -> every rank solves its rows of panel p+1 -> all-gather
+                     (no un-permute behind it any more: the update kernels read the gathered panel in place; the replicated
+                     factor's copy of the panel is written on the main stream)
+  step time        = max(STRIP_B(p) + REST(p) [+ copy into the replicated factor], chain(p+1))
 (round 3 ran the whole STRIP first and the chain behind it: STRIP(p) + max(REST(p), chain(p+1)); the table carries that
 fit time in its own column.)
 """
@@ -52,7 +54,7 @@ def chain_time(idle_work, busy_for):
     return busy_for + idle_work - busy_for / CHAIN_STRETCH
 
 
-def fit_time(N, P, nb=None, split=True):
+def fit_time(N, P, nb=None, split=True, replicated=True):
     nb = nb or pick_nb(N, P)
     rate = RATE[nb] if P > 1 else RATE_1GPU
     nblk = N // nb
@@ -78,14 +80,15 @@ def fit_time(N, P, nb=None, split=True):
         if split:   # round 4: only the next diagonal block's update on the chain; the rest of the strip with the REST
             strip_d = max(STRIP_D_FLOOR * nb / 1024, nb * (nb + 1.0) * nb / 30e12)
             strip_b = max(0.0, 2.0 * (n - nb) * nb * nb / P / rate)
-            main = strip_b + rest
-            ch = strip_d + chain_time(diag_idle, main) + bcast + solve + gather + unperm
+            main = strip_b + rest + (unperm if replicated else 0.0)   # panel p into the full factor, off the chain
+            ch = strip_d + chain_time(diag_idle, main) + bcast + solve + gather
             step = max(main, ch)
             over = ch - main
         else:
-            ch = chain_time(diag_idle, rest) + bcast + solve + gather + unperm
-            step = strip + max(rest, ch)
-            over = ch - rest
+            rest_m = rest + (unperm if replicated else 0.0)   # (the copy into the full factor was always on the main stream)
+            ch = chain_time(diag_idle, rest_m) + bcast + solve + gather + unperm
+            step = strip + max(rest_m, ch)
+            over = ch - rest_m
         if over > 0:
             exposed += over
             if first_exposed is None:
@@ -118,8 +121,8 @@ def table(N, M, Ps, replicated, label):
     rows = []
     base = None
     for P in Ps:
-        f = fit_time(N, P)
-        f["fit_s_round3_schedule"] = fit_time(N, P, split=False)["fit_s"]
+        f = fit_time(N, P, replicated=replicated)
+        f["fit_s_round3_schedule"] = fit_time(N, P, split=False, replicated=replicated)["fit_s"]
         pr = predict_time(N, M, P, replicated and P > 1) if P > 1 else predict_time(N, M, 1, True)
         extra = (ZSOLVE if replicated or P == 1 else 2 * (N // f["nb"]) * (LAT + 35e-6))   # alpha solves (distributed: not overlapped)
         tot = f["fit_s"] + pr + extra
