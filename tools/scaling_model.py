@@ -11,8 +11,8 @@ Schedule modelled (csrc/gpx_shard.inc, round 4): row blocks of height nb dealt b
   look-ahead stream: STRIP_D(p) (the next diagonal block only, on its owner) -> diagonal block p+1 -> broadcast
                      [L_pp | inverses | W_p] -> every rank solves its rows of panel p+1 -> all-gather
                      (no un-permute behind it any more: the update kernels read the gathered panel in place; the replicated
-                     factor's copy of the panel is written on the main stream)
-  step time        = max(STRIP_B(p) + REST(p) [+ copy into the replicated factor], chain(p+1))
+                     factor's copy of the panel is written on the copy stream beside the REST)
+  step time        = max(STRIP_B(p) + REST(p), chain(p+1))
 (round 3 ran the whole STRIP first and the chain behind it: STRIP(p) + max(REST(p), chain(p+1)); the table carries that
 fit time in its own column.)
 """
@@ -80,7 +80,7 @@ def fit_time(N, P, nb=None, split=True, replicated=True):
         if split:   # round 4: only the next diagonal block's update on the chain; the rest of the strip with the REST
             strip_d = max(STRIP_D_FLOOR * nb / 1024, nb * (nb + 1.0) * nb / 30e12)
             strip_b = max(0.0, 2.0 * (n - nb) * nb * nb / P / rate)
-            main = strip_b + rest + (unperm if replicated else 0.0)   # panel p into the full factor, off the chain
+            main = strip_b + rest   # (replicated: panel p goes into the full factor on the copy stream, beside the REST)
             ch = strip_d + chain_time(diag_idle, main) + bcast + solve + gather
             step = max(main, ch)
             over = ch - main
