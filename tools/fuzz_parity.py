@@ -75,7 +75,7 @@ def one_case(rng, c):
                  "alpha": float(np.max(np.abs(gp.alpha_ - ref.alpha_)) / np.max(np.abs(ref.alpha_))),
                  "logdet": float(abs(gp.log_det_ - ref.log_det_) / abs(ref.log_det_)),
                  "mean_only": float(np.max(np.abs(m2 - mean)) / max(np.max(np.abs(mean)), 1e-30)), "grad": 0.0, "one_pass": 0.0}
-            if c % 2 == 0:       # every other case: fit + predict as one pass (falls back to two calls for groups), then
+            if c % 2 == 0:       # every other case: fit + predict as one pass (groups: through the sharded factorisation unless split=0), then
                 m1, v1 = gp.fit_predict(X_in, y_in, Xs_in)    # everything below runs on the handle it leaves behind
                 e["one_pass"] = float(max(np.max(np.abs(m1 - mr)) / max(np.max(np.abs(mr)), 1e-30), np.max(np.abs(v1 - vr)) / sf2))
             if N <= 1600 and dtype == "float64":   # round 3: also when the factor is only held distributed (ndev > 1, repl 0)
