@@ -82,9 +82,11 @@ def synthetic(N, d, M, seed):
 
 
 def shard_block(N, world):
-    """Row-block height the library picks for the shard (gpx_shard.inc: >= 16 blocks per rank)."""
+    """Row-block height the library picks for the shard (gpx_shard.inc: >= 8 blocks per rank under the snake dealing of
+    round 4, >= 16 under GPX_SHARD_DEAL=cyclic)."""
     nb = 1024
-    while nb > 256 and nb * 16 * world > N:
+    per_rank = 16 if os.environ.get("GPX_SHARD_DEAL", "snake") in ("cyclic", "0") else 8
+    while nb > 256 and nb * per_rank * world > N:
         nb //= 2
     return int(os.environ.get("GPX_NB_SHARD", nb))
 

@@ -84,6 +84,10 @@ SIGNATURES = {
     "gpx_gemm_nt": (C.c_int, [_PD, C.c_int64, C.c_int64, _PD, _PD, C.c_int64, C.c_int32]),
     "gpx_debug_tile_map": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                      C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]),
+    "gpx_debug_stair_map": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]),
+    "gpx_debug_deal": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int64)]),
     "gpx_debug_local_hub": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "gpx_debug_set_delay": (C.c_int, [C.c_uint64]),
     "gpx_debug_gemm_bench": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

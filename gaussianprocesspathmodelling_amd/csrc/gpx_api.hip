@@ -121,6 +121,7 @@ struct gpx_handle {
   const void* Lfac = nullptr;  // the factor the single-GPU solves read: K (unsharded) or Lfull
   // device-flag hand-overs between this handle's streams (diag_enqueue, fused strip): -1 not probed yet, 1 a kernel parked
   // on one stream sees the store of a kernel launched later on another (flag_handover_probe), 0 it does not: hipEvents
+  int shard_snake = 1;  // the dealing of row blocks the last sharded fit used (gpx_internal.h: Deal)
   int64_t fq_rows = 0;  // gpx_fit_predict on a shard: padded rows of this rank's slice of the query points (bordered rows of its K buffer)
   int flag_ok = -1;
   int flag_retries = 0;  // fits of this handle that were run again with hipEvents after a parked stream timed out
@@ -1565,10 +1566,10 @@ int mixed_fit(gpx_handle* h, const void* X, const void* y, int64_t N, int32_t d,
     launch_rows_f64_to_f32(R64, Npad, (float*)h->RT32.p, ld32, k, RHS_ROWS, N, Npad, st);
     if (dist) {  // own column blocks of the residual rows -> the distributed solve -> delta replicated in RT32 again
       const int nb = h->nb_shard;
-      const Shard sh{h->comm->world, h->comm->rank, nb, Npad / nb};
+      const Shard sh{h->comm->world, h->comm->rank, nb, Npad / nb, h->shard_snake};
       float* Rl = (float*)h->RTloc.p;
       for (int64_t lb = 0; lb < sh.nlb(sh.r); ++lb)
-        HIPCHK(h, hipMemcpy2DAsync(Rl + lb * nb, (size_t)h->ldy * 4, (const float*)h->RT32.p + (lb * sh.P + sh.r) * nb,
+        HIPCHK(h, hipMemcpy2DAsync(Rl + lb * nb, (size_t)h->ldy * 4, (const float*)h->RT32.p + sh.global(sh.r, lb) * nb,
                                    (size_t)ld32 * 4, (size_t)nb * 4, RHS_ROWS, hipMemcpyDeviceToDevice, st));
       if ((rc = shard_solve_dist<float>(h, sh, Rl, (float*)h->RT32.p))) return rc;
     } else if (few) {
@@ -2337,9 +2338,41 @@ int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t 
                        int64_t cap, int64_t* count) try {
   if (!out || !count || tm <= 0 || cap <= 0 || kind < 0 || kind > 2) return GPX_E_ARG;
   if (kind == 1 && (tn <= 0 || P <= 0 || tpb <= 0 || c < 0)) return GPX_E_ARG;
-  const int64_t n = debug_tile_map(kind, tm, tn, P, tpb, c, out, cap);
+  BcMask bc{P, tpb};  // cyclic dealing in its old shorthand: row block of local block j = j P + c
+  bc.gc0 = -c;
+  const int64_t n = debug_tile_map(kind, tm, tn, bc, out, cap);
   if (n < 0) return GPX_E_ARG;
   *count = n;
+  return GPX_OK;
+}
+GPX_CATCH_ALL
+
+int gpx_debug_stair_map(int64_t tm, int64_t tn, int32_t P, int32_t tpb, int32_t r, int32_t lbf, int32_t gc0,
+                        int32_t snake, int32_t* out, int64_t cap, int64_t* count) try {
+  if (!out || !count || tm <= 0 || tn <= 0 || cap <= 0 || P <= 0 || tpb <= 0 || r < 0 || r >= P || lbf < 0 || gc0 < 0)
+    return GPX_E_ARG;
+  BcMask bc{P, tpb};
+  bc.r = r;
+  bc.lbf = lbf;
+  bc.gc0 = gc0;
+  bc.snake = snake ? 1 : 0;
+  if (bc.row_tile(0) < 0) return GPX_E_ARG;  // the first local row block must not lie left of the first column block
+  const int64_t n = debug_tile_map(1, tm, tn, bc, out, cap);
+  if (n < 0) return GPX_E_ARG;
+  *count = n;
+  return GPX_OK;
+}
+GPX_CATCH_ALL
+
+int gpx_debug_deal(int32_t P, int32_t snake, int64_t nblk, int32_t* owner, int64_t* local, int64_t* upto) try {
+  if (P <= 0 || nblk <= 0 || !owner || !local || !upto) return GPX_E_ARG;
+  const Deal dl{P, snake ? 1 : 0};
+  for (int64_t g = 0; g < nblk; ++g) {
+    owner[g] = dl.owner(g);
+    local[g] = dl.local(g);
+    if (dl.global(owner[g], local[g]) != g) return GPX_E_ARG;  // the two directions must agree
+    for (int r = 0; r < P; ++r) upto[g * P + r] = dl.upto(g, r);
+  }
   return GPX_OK;
 }
 GPX_CATCH_ALL

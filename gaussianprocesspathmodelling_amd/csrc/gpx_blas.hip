@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256, (BT == 64 && KSUB >= 4) ? 1 : 2) void gemm_nt_
 }
 
 // ---- the sharded trailing update: C -= A * B^T under the block-cyclic row map ----------
-// Local tile row ti stands for global tile row lim(ti) = ((ti/tpb)*P + c)*tpb + ti%tpb of the
-// trailing matrix and owns the tiles tj <= lim(ti): a staircase.  Launching the bounding
+// Local tile row ti stands for tile row lim(ti) = BcMask::row_tile(ti) of the trailing matrix (its row block's
+// place in the dealing, gpx_tile.h: Deal) and owns the tiles tj <= lim(ti): a staircase.  Launching the bounding
 // rectangle leaves half of the XCD chunks empty (measured: 37.7 TF where the triangular
 // enumeration of the unsharded path gets 68), so the host counts, per super-row of 8 tile rows, the
 // 8x8 super-tiles all its rows own completely plus its ragged remainder in single tiles
@@ -372,7 +372,7 @@ struct StairMap {
 
 // columns owned by local tile row ti (clipped to the launch): tj <= stair_lim
 __host__ __device__ __forceinline__ int stair_lim(const BcMask& bc, int ti, int tiles_n) {
-  const int lim = ((ti / bc.tpb) * bc.P + bc.c) * bc.tpb + ti % bc.tpb;
+  const int lim = bc.row_tile(ti);
   return lim < tiles_n - 1 ? lim : tiles_n - 1;
 }
 
@@ -1344,14 +1344,9 @@ unsigned launch_gemm_nt_fused(T* C, int64_t ldc, const T* P, int64_t ldp, int64_
 
 template <typename T>
 void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
-                       int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c, hipStream_t st, int g0, int p,
-                       int64_t piece) {
+                       int64_t n, int64_t k, const BcMask& bc, hipStream_t st) {
   debug_delay(st);
   if (m <= 0 || n <= 0) return;
-  BcMask bc{bc_P, bc_tpb, bc_c};
-  bc.g0 = g0;  // piece > 0: B is the all-gathered panel in rank-major order (bc_brow)
-  bc.p = p;
-  bc.piece = piece;
   const int64_t tm = m / 128, tn = n / 128;
   const int64_t nsr = (tm + 7) / 8;
   if (nsr > STAIR_MAX) {  // beyond the by-value map: bounding rectangle with the mask
@@ -1381,7 +1376,7 @@ void launch_gemm_nn(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int6
 // triangle of a tm x tm tile grid; kind 1: block-cyclic staircase (bc) of a tm x tn grid.
 // Writes (ti, tj) pairs of the valid slots; returns their number, or -1 if cap is too small
 // or the staircase needs more than STAIR_MAX super-rows.
-int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, int bc_c, int32_t* out,
+int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, const BcMask& bc, int32_t* out,
                        int64_t cap) {
   int64_t n = 0;
   if (kind == 0) {
@@ -1410,7 +1405,6 @@ int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, i
       ++n;
     }
   } else {
-    const BcMask bc{bc_P, bc_tpb, bc_c};
     if ((tm + 7) / 8 > STAIR_MAX) return -1;
     StairMap map;
     const unsigned grid = build_stair_map(bc, tm, tn, map);
@@ -1451,7 +1445,7 @@ extern "C" int gpx_debug_read_syrk_clock(long long* out) {
   template unsigned launch_gemm_nt_fused<T>(T*, int64_t, const T*, int64_t, int64_t, int64_t, int64_t,  \
                                             unsigned*, hipStream_t);                                    \
   template void launch_gemm_nt_bc<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,        \
-                                     int64_t, int64_t, int, int, int, hipStream_t, int, int, int64_t);  \
+                                     int64_t, int64_t, const BcMask&, hipStream_t);                     \
   template void launch_gemm_nn<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t, int64_t,  \
                                   int64_t, hipStream_t);                                                \
   template void launch_gemm_nt_splitk<T>(T*, int64_t, const T*, int64_t, const T*, int64_t, int64_t,    \

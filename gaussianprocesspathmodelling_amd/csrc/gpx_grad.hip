@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void kinv_trace_kernel(const double* __rest
                                                             const double* __restrict__ Xs, int d_rt, int ard,
                                                             double sf2, double sn2, double* __restrict__ part,
                                                             int ntheta, int64_t nslots, int P, int rank,
-                                                            int dc_nb, int dc_P, int dc_r, int64_t dc_cols) {
+                                                            int dc_nb, int dc_P, int dc_r, int64_t dc_cols, int dc_snake) {
   constexpr int BT = 128;
   __shared__ __attribute__((aligned(16))) double smem[TileShapeG<double, BT, BT>::SMEM_ELEMS];
   __shared__ double red[4];
@@ -82,14 +82,14 @@ __global__ __launch_bounds__(256, 2) void kinv_trace_kernel(const double* __rest
   zero_acc(acc);
   // rows ti, tj of ZT are zero left of column ti*BT (tj <= ti): start the contraction there.
   // Distributed-column mode (dc_P > 0; the factor is only held distributed): this rank holds the
-  // columns of L^-T that belong to ITS row blocks of L (height dc_nb, global block g = lb dc_P + dc_r
+  // columns of L^-T that belong to ITS row blocks of L (height dc_nb, its block number lb — Deal.global(dc_r, lb) —
   // at local column lb dc_nb) for ALL rows, and contributes the part of the contraction over those
   // columns; the first own block that is not left of the tile's rows starts it.  The partial sums of
   // the ranks add up to the trace (one all-reduce of ntheta numbers).
   int64_t koff = (int64_t)ti * BT, klen = npad - koff;
   if (dc_P > 0) {
     const int64_t gi = koff / dc_nb;                                        // block of the tile's first row
-    const int64_t before = gi > dc_r ? (gi - dc_r + dc_P - 1) / dc_P : 0;   // own blocks with index < gi
+    const int64_t before = Deal{dc_P, dc_snake}.upto(gi - 1, dc_r);         // own blocks with index < gi
     koff = before * dc_nb;
     klen = dc_cols - koff;
     if (klen <= 0) return;  // nothing of this tile lives here (its slot of `part` was zeroed)
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void set_diag_one_kernel(double* A, int64_t ld
 template <int KERNEL>
 void launch_kinv_trace_k(const double* ZT, int64_t ld, int64_t npad, int64_t n, const double* Xs, int d, int ard,
                          double sf2, double sn2, double* part, int ntheta, int P, int rank, int dc_nb, int dc_P,
-                         int dc_r, int64_t dc_cols, hipStream_t st) {
+                         int dc_r, int64_t dc_cols, int dc_snake, hipStream_t st) {
   const int tiles = (int)(npad / 128);
   const int64_t ts = (tiles + 7) / 8;
   const int64_t nslots = ts * (ts - 1) / 2 * 64 + ts * 36;
@@ -317,10 +317,10 @@ void launch_kinv_trace_k(const double* ZT, int64_t ld, int64_t npad, int64_t n, 
   if (mine == 0) return;
   dim3 grid((unsigned)(mine * 512)), block(256);  // whole octets of 8 x 64 slots
   switch (d) {
-    case 1: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 1>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank, dc_nb, dc_P, dc_r, dc_cols); break;
-    case 2: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 2>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank, dc_nb, dc_P, dc_r, dc_cols); break;
-    case 3: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 3>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank, dc_nb, dc_P, dc_r, dc_cols); break;
-    default: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 0>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank, dc_nb, dc_P, dc_r, dc_cols); break;
+    case 1: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 1>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank, dc_nb, dc_P, dc_r, dc_cols, dc_snake); break;
+    case 2: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 2>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank, dc_nb, dc_P, dc_r, dc_cols, dc_snake); break;
+    case 3: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 3>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank, dc_nb, dc_P, dc_r, dc_cols, dc_snake); break;
+    default: hipLaunchKernelGGL((kinv_trace_kernel<KERNEL, 0>), grid, block, 0, st, ZT, ld, tiles, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, nslots, P, rank, dc_nb, dc_P, dc_r, dc_cols, dc_snake); break;
   }
 }
 
@@ -354,18 +354,18 @@ void launch_set_diag_one(double* A, int64_t lda, int64_t n, hipStream_t st) {
 void launch_kinv_trace(int kernel, const double* ZT, int64_t ld, int64_t npad, int64_t n, const double* Xs, int d,
                        int ard, double sf2, double sn2, double* part, int ntheta, int P, int rank, hipStream_t st) {
   if (kernel == 0)
-    launch_kinv_trace_k<0>(ZT, ld, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, P, rank, 0, 0, 0, 0, st);
+    launch_kinv_trace_k<0>(ZT, ld, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, P, rank, 0, 0, 0, 0, 0, st);
   else
-    launch_kinv_trace_k<1>(ZT, ld, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, P, rank, 0, 0, 0, 0, st);
+    launch_kinv_trace_k<1>(ZT, ld, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, P, rank, 0, 0, 0, 0, 0, st);
 }
 
 void launch_kinv_trace_cols(int kernel, const double* ZTc, int64_t ldc, int64_t npad, int64_t n, const double* Xs,
                             int d, int ard, double sf2, double sn2, double* part, int ntheta, int nb, int P, int rank,
-                            int64_t ncols, hipStream_t st) {
+                            int64_t ncols, int snake, hipStream_t st) {
   if (kernel == 0)
-    launch_kinv_trace_k<0>(ZTc, ldc, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, 1, 0, nb, P, rank, ncols, st);
+    launch_kinv_trace_k<0>(ZTc, ldc, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, 1, 0, nb, P, rank, ncols, snake, st);
   else
-    launch_kinv_trace_k<1>(ZTc, ldc, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, 1, 0, nb, P, rank, ncols, st);
+    launch_kinv_trace_k<1>(ZTc, ldc, npad, n, Xs, d, ard, sf2, sn2, part, ntheta, 1, 0, nb, P, rank, ncols, snake, st);
 }
 
 void launch_alpha_quad(int kernel, const double* alphaT, int64_t ld, int k, int64_t npad, int64_t n,

@@ -26,6 +26,61 @@ static_assert(ld_skew<double>() * sizeof(double) % 128 == 0 && ld_skew<float>() 
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Dealing of the row blocks of the Gram matrix over the P ranks of a shard (csrc/gpx_shard.inc).
+//   cyclic (rounds 1-3): block g on rank g mod P — rank P-1 holds the lowest block of every round of P, and a row block's
+//     share of every trailing update grows with its index: the last rank carries 8.4 % more than the mean at P = 8 /
+//     nb = 512 (N = 65536), 17 % at nb = 1024, in EVERY panel (the ranks meet at each panel, so that is the fit's time).
+//   snake (round 4, default): rounds of 2 P blocks dealt 0, 1, ..., P-1, P-1, ..., 1, 0 — every rank gets one block of the
+//     ascending and one of the descending half, the sums agree: 0.65 % / 2.6 % in the same cases (tools/scaling_model.py).
+// Everything that depends on the dealing asks this struct (host and device).
+struct Deal {
+  int P, snake;
+  __host__ __device__ __forceinline__ int owner(int64_t g) const {
+    if (!snake) return (int)(g % P);
+    const int pos = (int)(g % (2 * P));
+    return pos < P ? pos : 2 * P - 1 - pos;
+  }
+  __host__ __device__ __forceinline__ int64_t local(int64_t g) const {  // index of block g among its owner's blocks
+    if (!snake) return g / P;
+    return 2 * (g / (2 * P)) + ((g % (2 * P)) >= P ? 1 : 0);
+  }
+  __host__ __device__ __forceinline__ int64_t global(int r, int64_t lb) const {  // block number lb of rank r
+    if (!snake) return lb * P + r;
+    return (lb >> 1) * (2 * P) + ((lb & 1) ? 2 * P - 1 - r : r);
+  }
+  __host__ __device__ __forceinline__ int64_t upto(int64_t p, int r) const {  // blocks of rank r with index <= p (p >= -1)
+    if (!snake) return p >= r ? (p - r) / P + 1 : 0;
+    const int64_t n = p + 1, c = n / (2 * P), rem = n % (2 * P);
+    return 2 * c + (rem > r ? 1 : 0) + (rem > 2 * P - 1 - r ? 1 : 0);
+  }
+};
+
+struct BcMask {   // row map of the sharded trailing update (P == 0: unused)
+  int P, tpb;     // ranks, tiles per block
+  int r = 0, lbf = 0, gc0 = 0, snake = 0;  // local tile row ti belongs to row block Deal.global(r, lbf + ti / tpb) of the matrix,
+                                           // tile column 0 to block gc0: row tile (that block - gc0) * tpb + ti % tpb of the launch
+  // B operand read straight from the ALL-GATHERED panel (round 4; piece == 0: B is contiguous): rank-major pieces of
+  // `piece` rows, every rank's own blocks beyond panel p in order.  Tile column tj is block g = gc0 + tj / tpb of the
+  // matrix: block number local(g) - upto(p, owner(g)) of the piece of rank owner(g).
+  int p = 0;
+  int64_t piece = 0;
+  __host__ __device__ __forceinline__ Deal deal() const { return Deal{P, snake}; }
+  __host__ __device__ __forceinline__ int row_tile(int ti) const {  // launch-relative tile row of local tile row ti
+    return (int)(deal().global(r, lbf + ti / tpb) - gc0) * tpb + ti % tpb;
+  }
+};
+
+// first row of B's tile column tj (BT rows per tile; tpb counts BT-tiles per block)
+template <int BT>
+__host__ __device__ __forceinline__ int64_t bc_brow(const BcMask& bc, int tj) {
+  if (bc.piece == 0) return (int64_t)tj * BT;
+  const Deal dl = bc.deal();
+  const int64_t g = bc.gc0 + tj / bc.tpb;
+  const int rr = dl.owner(g);
+  return (int64_t)rr * bc.piece + ((dl.local(g) - dl.upto(bc.p, rr)) * bc.tpb + tj % bc.tpb) * BT;
+}
+
+
 // ---- kernel-matrix build (gpx_kbuild.hip) ---------------------------------------
 // Xs = X / lengthscale (per-dimension), rows >= n zero-filled up to npad.
 template <typename T>
@@ -119,7 +174,8 @@ void launch_wait_counter(const unsigned* ctr, unsigned target, int* info, hipStr
 void launch_flag_probe_wait(const unsigned* flag, unsigned* seen, unsigned max_polls, hipStream_t st);
 void launch_flag_probe_set(unsigned* flag, hipStream_t st);
 // Sharded trailing update: C (m local rows x n, 128-tiles) -= A B^T restricted to tiles with
-//   tile_col <= ((tile_row / tpb) * P + c) * tpb + tile_row % tpb   (block-cyclic rows).
+//   tile_col <= bc.row_tile(tile_row)   (the row blocks' places in the dealing: Deal / BcMask above);
+//   bc.piece > 0: B is the all-gathered panel bc.p in rank-major pieces (bc_brow).
 // test hook: random spin kernels in front of launches (gpx_debug_set_delay; gpx_misc.hip)
 void debug_set_delay(uint64_t seed);
 void debug_delay(hipStream_t st);
@@ -131,8 +187,7 @@ void launch_gemm_nt_splitk(T* C, int64_t ldc, const T* A, int64_t lda, const T* 
                            int64_t n, int64_t k, int S, T* part, int64_t ldp, hipStream_t st);
 template <typename T>
 void launch_gemm_nt_bc(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
-                       int64_t n, int64_t k, int bc_P, int bc_tpb, int bc_c, hipStream_t st, int g0 = 0, int p = 0,
-                       int64_t piece = 0);  // piece > 0: B = the all-gathered panel p in rank-major pieces, tile column 0 = block g0
+                       int64_t n, int64_t k, const BcMask& bc, hipStream_t st);
 // C (m x n, ldc) -= A (m x k, lda) * B (k x n, ldb); 64x64 tiles.
 template <typename T>
 void launch_gemm_nn(T* C, int64_t ldc, const T* A, int64_t lda, const T* B, int64_t ldb, int64_t m,
@@ -162,7 +217,7 @@ void launch_logdet(const T* A, int64_t lda, int64_t n, double* out, hipStream_t 
 void launch_mfma_probe(const double* A, const double* B, double* D, hipStream_t st);
 void launch_mfma_probe_f32(const float* A, const float* B, float* D, hipStream_t st);
 void launch_mfma_loop(double* sink, int iters, int blocks, hipStream_t st);
-int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, int bc_P, int bc_tpb, int bc_c, int32_t* out,
+int64_t debug_tile_map(int kind, int64_t tm, int64_t tn, const BcMask& bc, int32_t* out,
                        int64_t cap);
 void launch_copy(const double* src, double* dst, int64_t count, hipStream_t st);
 
@@ -181,7 +236,7 @@ void launch_kinv_trace(int kernel, const double* ZT, int64_t ld, int64_t npad, i
 // rank visits every tile and contracts over its own columns: the ranks' partial sums add up
 void launch_kinv_trace_cols(int kernel, const double* ZTc, int64_t ldc, int64_t npad, int64_t n, const double* Xs,
                             int d, int ard, double sf2, double sn2, double* part, int ntheta, int nb, int P, int rank,
-                            int64_t ncols, hipStream_t st);
+                            int64_t ncols, int snake, hipStream_t st);
 // part[slot][t] = sum over the tile of (sum_c alpha_ic alpha_jc) (dK/dlog theta_t)_ij, alphaT (k x npad, ld)
 void launch_alpha_quad(int kernel, const double* alphaT, int64_t ld, int k, int64_t npad, int64_t n,
                        const double* Xs, int d, int ard, double sf2, double sn2, double* part, int ntheta,
@@ -226,15 +281,15 @@ void launch_fix_diag(T* A, int64_t lda, int n, int nvalid, double add, hipStream
 // -> dst [(nblk-p-1)*nb][ldd] in global row order (the replicated factor's column block p: the update kernels read
 // the gathered panel in place, bc_brow in gpx_tile.h).
 template <typename T>
-void launch_unpermute_panel(const T* G, int64_t ldp, T* dst, int64_t ldd, int nb, int P, int p, int nblk, int64_t maxcnt,
+void launch_unpermute_panel(const T* G, int64_t ldp, T* dst, int64_t ldd, int nb, Deal dl, int p, int nblk, int64_t maxcnt,
                             hipStream_t st);
-// YTloc[r][lb*nb + i] = y[(g*nb+i)*k + r] for the blocks g = rank + lb*P owned by `rank`.
+// YTloc[r][lb*nb + i] = y[(g*nb+i)*k + r] for the blocks g = dl.global(rank, lb) owned by `rank`.
 template <typename T>
-void launch_pack_rhs_local(const T* y, int64_t n, int k, T* YTloc, int64_t ldy, int nb, int nlb, int P, int rank, int R,
+void launch_pack_rhs_local(const T* y, int64_t n, int k, T* YTloc, int64_t ldy, int nb, int nlb, Deal dl, int rank, int R,
                            hipStream_t st);
 // Full[r][g*nb + i] = Loc[r][lb*nb + i] (own blocks), rest untouched.
 template <typename T>
-void launch_scatter_local(const T* Loc, int64_t ldl, T* Full, int64_t ldf, int nb, int nlb, int P, int rank, int R,
+void launch_scatter_local(const T* Loc, int64_t ldl, T* Full, int64_t ldf, int nb, int nlb, Deal dl, int rank, int R,
                           hipStream_t st);
 // dst (rows x cols, ldd) += sign * src (rows x cols, lds)
 template <typename T>

@@ -154,14 +154,13 @@ __global__ __launch_bounds__(256) void fix_diag_kernel(T* A, int64_t lda, int n,
 
 template <typename T>
 __global__ __launch_bounds__(256) void unpermute_panel_kernel(const T* __restrict__ G, int64_t ldp, T* __restrict__ Pglob,
-                                                             int64_t ldd, int nb, int P, int p, int64_t maxcnt) {
+                                                             int64_t ldd, int nb, Deal dl, int p, int64_t maxcnt) {
   // blockIdx.y = trailing block b (global block g = p+1+b), blockIdx.x strides rows of the block
   typedef float v4 __attribute__((ext_vector_type(4)));  // 16-byte pieces whatever the element type
   constexpr int E = 16 / (int)sizeof(T);
   const int g = p + 1 + blockIdx.y;
-  const int rr = g % P;
-  const int lb0 = (p >= rr) ? (p - rr) / P + 1 : 0;
-  const int64_t src_row0 = (int64_t)rr * maxcnt + (int64_t)(g / P - lb0) * nb;
+  const int rr = dl.owner(g);
+  const int64_t src_row0 = (int64_t)rr * maxcnt + (dl.local(g) - dl.upto(p, rr)) * nb;
   const int64_t dst_row0 = (int64_t)blockIdx.y * nb;
   const int c2 = nb / E;  // pieces per row
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)nb * c2;
@@ -175,24 +174,24 @@ __global__ __launch_bounds__(256) void unpermute_panel_kernel(const T* __restric
 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_rhs_local_kernel(const T* __restrict__ y, int64_t n, int k, T* __restrict__ YTloc,
-                                                            int64_t ldy, int nb, int nlb, int P, int rank) {
+                                                            int64_t ldy, int nb, int nlb, Deal dl, int rank) {
   const int r = blockIdx.y;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < (int64_t)nlb * nb;
        j += (int64_t)gridDim.x * 256) {
     const int64_t lb = j / nb;
-    const int64_t gi = (lb * P + rank) * nb + (j - lb * nb);
+    const int64_t gi = dl.global(rank, lb) * nb + (j - lb * nb);
     YTloc[(int64_t)r * ldy + j] = (r < k && gi < n) ? y[gi * k + r] : (T)0;
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_local_kernel(const T* __restrict__ Loc, int64_t ldl, T* __restrict__ Full,
-                                                           int64_t ldf, int nb, int nlb, int P, int rank) {
+                                                           int64_t ldf, int nb, int nlb, Deal dl, int rank) {
   const int r = blockIdx.y;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < (int64_t)nlb * nb;
        j += (int64_t)gridDim.x * 256) {
     const int64_t lb = j / nb;
-    const int64_t gi = (lb * P + rank) * nb + (j - lb * nb);
+    const int64_t gi = dl.global(rank, lb) * nb + (j - lb * nb);
     Full[(int64_t)r * ldf + gi] = Loc[(int64_t)r * ldl + j];
   }
 }
@@ -247,27 +246,27 @@ void launch_fix_diag(T* A, int64_t lda, int n, int nvalid, double add, hipStream
 }
 
 template <typename T>
-void launch_unpermute_panel(const T* G, int64_t ldp, T* dst, int64_t ldd, int nb, int P, int p, int nblk, int64_t maxcnt,
+void launch_unpermute_panel(const T* G, int64_t ldp, T* dst, int64_t ldd, int nb, Deal dl, int p, int nblk, int64_t maxcnt,
                             hipStream_t st) {
   const int ntb = nblk - p - 1;
   if (ntb <= 0) return;
-  hipLaunchKernelGGL(unpermute_panel_kernel<T>, dim3(64, (unsigned)ntb), dim3(256), 0, st, G, ldp, dst, ldd, nb, P, p, maxcnt);
+  hipLaunchKernelGGL(unpermute_panel_kernel<T>, dim3(64, (unsigned)ntb), dim3(256), 0, st, G, ldp, dst, ldd, nb, dl, p, maxcnt);
 }
 
 template <typename T>
-void launch_pack_rhs_local(const T* y, int64_t n, int k, T* YTloc, int64_t ldy, int nb, int nlb, int P, int rank, int R,
+void launch_pack_rhs_local(const T* y, int64_t n, int k, T* YTloc, int64_t ldy, int nb, int nlb, Deal dl, int rank, int R,
                            hipStream_t st) {
   if (nlb <= 0) return;
   const int64_t bx = ((int64_t)nlb * nb + 255) / 256;
-  hipLaunchKernelGGL(pack_rhs_local_kernel<T>, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, y, n, k, YTloc, ldy, nb, nlb, P, rank);
+  hipLaunchKernelGGL(pack_rhs_local_kernel<T>, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, y, n, k, YTloc, ldy, nb, nlb, dl, rank);
 }
 
 template <typename T>
-void launch_scatter_local(const T* Loc, int64_t ldl, T* Full, int64_t ldf, int nb, int nlb, int P, int rank, int R,
+void launch_scatter_local(const T* Loc, int64_t ldl, T* Full, int64_t ldf, int nb, int nlb, Deal dl, int rank, int R,
                           hipStream_t st) {
   if (nlb <= 0) return;
   const int64_t bx = ((int64_t)nlb * nb + 255) / 256;
-  hipLaunchKernelGGL(scatter_local_kernel<T>, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, Loc, ldl, Full, ldf, nb, nlb, P, rank);
+  hipLaunchKernelGGL(scatter_local_kernel<T>, dim3((unsigned)(bx > 1024 ? 1024 : bx), (unsigned)R), dim3(256), 0, st, Loc, ldl, Full, ldf, nb, nlb, dl, rank);
 }
 
 template <typename T>
@@ -426,9 +425,9 @@ void launch_logdet(const T* A, int64_t lda, int64_t n, double* out, hipStream_t 
   template void launch_set_diag_one_t<T>(T*, int64_t, int64_t, hipStream_t);                        \
   template void launch_copy2d<T>(T*, int64_t, const T*, int64_t, int64_t, int64_t, hipStream_t);           \
   template void launch_fix_diag<T>(T*, int64_t, int, int, double, hipStream_t);                           \
-  template void launch_unpermute_panel<T>(const T*, int64_t, T*, int64_t, int, int, int, int, int64_t, hipStream_t); \
-  template void launch_pack_rhs_local<T>(const T*, int64_t, int, T*, int64_t, int, int, int, int, int, hipStream_t); \
-  template void launch_scatter_local<T>(const T*, int64_t, T*, int64_t, int, int, int, int, int, hipStream_t); \
+  template void launch_unpermute_panel<T>(const T*, int64_t, T*, int64_t, int, Deal, int, int, int64_t, hipStream_t); \
+  template void launch_pack_rhs_local<T>(const T*, int64_t, int, T*, int64_t, int, int, Deal, int, int, hipStream_t); \
+  template void launch_scatter_local<T>(const T*, int64_t, T*, int64_t, int, int, Deal, int, int, hipStream_t); \
   template void launch_add_block<T>(T*, int64_t, const T*, int64_t, int, int, double, hipStream_t);        \
   template void launch_add_scalar<T>(T*, int64_t, double, hipStream_t);                                    \
   template void launch_reduce_ranks<T>(const T*, T*, int, int64_t, int, hipStream_t);                      \

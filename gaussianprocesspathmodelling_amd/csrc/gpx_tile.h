@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gpx_internal.h"
+
 namespace gpx {
 namespace {
 
@@ -261,25 +263,8 @@ __host__ __device__ __forceinline__ void tri_coords(int64_t t, int& ti, int& tj)
 //   !TRI: rectangular super-tile grid (sh x 64/sh tiles each); mask_lower 1 also drops
 //         tiles with tj > ti (look-ahead strip of the SYRK), 2 applies the block-cyclic
 //         row map of the sharded trailing update.
-struct BcMask {   // block-cyclic row map of the sharded trailing update (P == 0: unused)
-  int P, tpb, c;  // global row tile (relative to the trailing start) of local row tile ti:
-                  //   ((ti / tpb) * P + c) * tpb + ti % tpb
-  // B operand read straight from the ALL-GATHERED panel (round 4; piece == 0: B is contiguous): rank-major pieces of
-  // `piece` rows, rank rr's piece holding its own blocks beyond panel p in order.  Tile column tj of the launch is block
-  // g = g0 + tj / tpb of the matrix: block number g / P - lb0(p, g % P) of the piece of rank g % P.
-  int g0 = 0, p = 0;
-  int64_t piece = 0;
-};
-
-// first row of B's tile column tj (BT rows per tile; tpb counts BT-tiles per block)
-template <int BT>
-__host__ __device__ __forceinline__ int64_t bc_brow(const BcMask& bc, int tj) {
-  if (bc.piece == 0) return (int64_t)tj * BT;
-  const int g = bc.g0 + tj / bc.tpb, rr = g % bc.P;
-  const int lb0 = bc.p >= rr ? (bc.p - rr) / bc.P + 1 : 0;
-  return (int64_t)rr * bc.piece + ((int64_t)(g / bc.P - lb0) * bc.tpb + tj % bc.tpb) * BT;
-}
-
+// (Deal / BcMask / bc_brow — the dealing of row blocks over the ranks of a shard — live in gpx_internal.h: the host side
+//  of the shard uses them too)
 template <bool TRI>
 __host__ __device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, int tiles_n, int sh,
                                             int mask_lower, const BcMask& bc, int& ti, int& tj) {
@@ -316,7 +301,7 @@ __host__ __device__ __forceinline__ bool tile_coords(int64_t lin, int tiles_m, i
     tj = sc * sw + inner % sw;
     if (ti >= tiles_m || tj >= tiles_n) return false;
     if (mask_lower == 1) return tj <= ti;
-    if (mask_lower == 2) return tj <= ((ti / bc.tpb) * bc.P + bc.c) * bc.tpb + ti % bc.tpb;
+    if (mask_lower == 2) return tj <= bc.row_tile(ti);
     return true;
   }
 }

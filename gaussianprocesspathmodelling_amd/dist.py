@@ -92,16 +92,33 @@ class HostCollectives:
             raise _abi.GpxError(rc, lib.gpx_last_error(handle).decode())
 
 
-# ---- block-cyclic bookkeeping (mirror of struct Shard in csrc/gpx_shard.inc) -------------------
-def owner(g, P):
-    return g % P
+# ---- bookkeeping of the dealing (mirror of struct Deal in csrc/gpx_internal.h) ------------------------------------
+# snake (round 4, the library's default): rounds of 2 P row blocks dealt 0, 1, ..., P-1, P-1, ..., 1, 0 — a row block's
+# share of every trailing update grows with its index, so the cyclic dealing (block g on rank g mod P) loads the last rank
+# 8 % (P = 8, nb = 512, N = 65536) above the mean in every panel; the snake's pairs sum to the same index on every rank.
+def owner(g, P, snake=True):
+    if not snake:
+        return g % P
+    pos = g % (2 * P)
+    return pos if pos < P else 2 * P - 1 - pos
 
 
-def blocks_owned(rank, nblk, P):
+def local_index(g, P, snake=True):
+    """index of block g among its owner's blocks"""
+    if not snake:
+        return g // P
+    return 2 * (g // (2 * P)) + (1 if g % (2 * P) >= P else 0)
+
+
+def blocks_owned(rank, nblk, P, snake=True):
     """global block indices stored by `rank`, in local order"""
-    return list(range(rank, nblk, P))
+    return [g for g in range(nblk) if owner(g, P, snake) == rank]
 
 
-def lb0(p, rank, P):
+def lb0(p, rank, P, snake=True):
     """number of blocks owned by `rank` with global index <= p"""
-    return (p - rank) // P + 1 if p >= rank else 0
+    if not snake:
+        return (p - rank) // P + 1 if p >= rank else 0
+    n = p + 1
+    c, rem = divmod(n, 2 * P)
+    return 2 * c + (1 if rem > rank else 0) + (1 if rem > 2 * P - 1 - rank else 0)

@@ -244,6 +244,14 @@ int gpx_microbench(double* mfma_tflops, double* copy_gbs);
  * every owned tile must appear exactly once. */
 int gpx_debug_tile_map(int32_t kind, int64_t tm, int64_t tn, int32_t P, int32_t tpb, int32_t c,
                        int32_t* out, int64_t cap, int64_t* count);
+/* the staircase of a rank under either dealing of the row blocks (round 4; cyclic: block g on rank g mod P; snake: rounds
+ * of 2 P blocks dealt 0 .. P-1, P-1 .. 0 — balanced row work): local tile row ti belongs to block number lbf + ti / tpb of
+ * rank r, tile column 0 to block gc0 of the matrix.  Same output as gpx_debug_tile_map kind 1. */
+int gpx_debug_stair_map(int64_t tm, int64_t tn, int32_t P, int32_t tpb, int32_t r, int32_t lbf, int32_t gc0,
+                        int32_t snake, int32_t* out, int64_t cap, int64_t* count);
+/* the dealing itself: owner[g], local[g] (index of block g among its owner's blocks) for g < nblk, and
+ * upto[g * P + r] = number of blocks of rank r with index <= g.  Test hook (tests/test_tile_maps.py). */
+int gpx_debug_deal(int32_t P, int32_t snake, int64_t nblk, int32_t* owner, int64_t* local, int64_t* upto);
 /* host-only exercise of the rendezvous the LOCAL transport's rank threads use (no GPU needed):
  * P threads run `rounds` barrier rounds, each checking that every rank published the round
  * number; if abort_rank >= 0 that rank leaves at round abort_round and aborts the hub instead

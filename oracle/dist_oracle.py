@@ -45,8 +45,29 @@ class NumpyCollectives:
         return arr
 
 
+# the dealing of row blocks over the ranks: snake (rounds of 2 P blocks dealt 0 .. P-1, P-1 .. 0; gpx_internal.h: Deal) or
+# cyclic (block g on rank g mod P).  Module-level switch so that the schedule below reads as before.
+SNAKE = True
+
+
+def _owner(g, P):
+    if not SNAKE:
+        return g % P
+    pos = g % (2 * P)
+    return pos if pos < P else 2 * P - 1 - pos
+
+
+def _local(g, P):
+    if not SNAKE:
+        return g // P
+    return 2 * (g // (2 * P)) + (1 if g % (2 * P) >= P else 0)
+
+
 def _lb0(p, r, P):
-    return (p - r) // P + 1 if p >= r else 0
+    if not SNAKE:
+        return (p - r) // P + 1 if p >= r else 0
+    c, rem = divmod(p + 1, 2 * P)
+    return 2 * c + (1 if rem > r else 0) + (1 if rem > 2 * P - 1 - r else 0)
 
 
 def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb, one_pass=False):
@@ -59,7 +80,7 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb, one_pass=False
     N, M = len(X), len(Xs)
     Npad = -(-N // nb) * nb
     nblk = Npad // nb
-    own = list(range(r, nblk, P))
+    own = [g for g in range(nblk) if _owner(g, P) == r]
     nloc = len(own) * nb
     Xp = np.zeros((Npad, X.shape[1]))
     Xp[:N] = X
@@ -80,7 +101,7 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb, one_pass=False
         B[:, N:] = 0.0
     logdet = np.zeros(1)
     for p in range(nblk):
-        o, root, lo = p * nb, p % P, (p // P) * nb
+        o, root, lo = p * nb, _owner(p, P), _local(p, P) * nb
         D = np.zeros((nb, nb))
         if r == root:
             D[:] = cholesky(A[lo:lo + nb, o:o + nb], lower=True)
@@ -97,15 +118,15 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb, one_pass=False
         rows = nloc - l0 * nb
         if rows > 0:
             A[l0 * nb:nloc, o:o + nb] = solve_triangular(D, A[l0 * nb:nloc, o:o + nb].T, lower=True).T
-        maxcnt = max((len(range(rr, nblk, P)) - _lb0(p, rr, P)) * nb for rr in range(P))
+        maxcnt = max((_lb0(nblk - 1, rr, P) - _lb0(p, rr, P)) * nb for rr in range(P))
         send = np.zeros((maxcnt, nb))
         send[:rows] = A[l0 * nb:nloc, o:o + nb]
         parts = coll.allgather(send)
         Pg = np.zeros(((nblk - p - 1) * nb, nb))
         for b in range(nblk - p - 1):
             g = p + 1 + b
-            rr = g % P
-            idx = g // P - _lb0(p, rr, P)
+            rr = _owner(g, P)
+            idx = _local(g, P) - _lb0(p, rr, P)
             Pg[b * nb:(b + 1) * nb] = parts[rr][idx * nb:(idx + 1) * nb]
         for lb in range(l0, len(own)):
             g = own[lb]
@@ -122,7 +143,7 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb, one_pass=False
     Yp[:N, 0] = y
     z = local(Yp)
     for p in range(nblk):                      # forward: broadcast the solved block
-        o, root, lo = p * nb, p % P, (p // P) * nb
+        o, root, lo = p * nb, _owner(p, P), _local(p, P) * nb
         S = np.zeros((nb, 1))
         if r == root:
             z[lo:lo + nb] = solve_triangular(A[lo:lo + nb, o:o + nb], z[lo:lo + nb], lower=True)
@@ -140,7 +161,7 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb, one_pass=False
         coll.allreduce_sum(z_full)
     cneg = np.zeros((Npad, 1))
     for p in range(nblk - 1, -1, -1):          # backward: reduce the partial products
-        o, root, lo = p * nb, p % P, (p // P) * nb
+        o, root, lo = p * nb, _owner(p, P), _local(p, P) * nb
         if p + 1 < nblk:
             red = coll.reduce_sum(cneg[o:o + nb], root)
         if r == root:
@@ -172,7 +193,7 @@ def sharded_fit_predict(coll, X, y, Xs, kernel, ls, sf2, sn2, nb, one_pass=False
     coll.allreduce_sum(mean)
     V = Ks.copy()
     for p in range(nblk):
-        o, root, lo = p * nb, p % P, (p // P) * nb
+        o, root, lo = p * nb, _owner(p, P), _local(p, P) * nb
         S = np.zeros((M, nb))
         if r == root:
             V[:, lo:lo + nb] = solve_triangular(A[lo:lo + nb, o:o + nb], V[:, lo:lo + nb].T, lower=True).T

@@ -30,7 +30,9 @@ def main():
     ls, sf2, sn2 = (0.3, 0.2, 0.25), 1.5, 1e-2
     res = {}
     if mode == "oracle":
+        import oracle.dist_oracle as dist_oracle
         from oracle.dist_oracle import NumpyCollectives, sharded_fit_predict
+        dist_oracle.SNAKE = os.environ.get("GPX_SHARD_DEAL", "snake") != "cyclic"
         mean, var, alpha, logdet = sharded_fit_predict(NumpyCollectives(), X, y, Xs, kernel, ls, sf2, sn2, nb,
                                                        one_pass=os.environ.get("SHARD_ONE_PASS") == "1")
         res = dict(mean=mean, var=var, alpha=alpha, logdet=logdet)

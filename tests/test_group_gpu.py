@@ -466,3 +466,37 @@ def test_group_fit_predict_reports_a_bad_pivot_and_honours_the_switches(monkeypa
                 assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
             else:
                 assert np.max(np.abs(got[0] - base[0])) <= 1e-8 and np.max(np.abs(got[1] - base[1])) <= 1e-8
+
+
+@pytest.mark.parametrize("ndev,N,nb,repl", [(3, 4000, 256, 0), (4, 4000, 256, 1), (8, 6000, 128, 0), (5, 3000, 128, 1), (2, 700, 128, 0)])
+def test_group_snake_and_cyclic_dealing_agree(monkeypatch, ndev, N, nb, repl):
+    """Round 4: the row blocks are dealt over the ranks as a snake (rounds of 2 P blocks: 0 .. P-1, P-1 .. 0 — balanced row
+    work) instead of cyclically (GPX_SHARD_DEAL=cyclic keeps rounds 1-3's dealing).  Who owns a row block changes no
+    operand and no order of any element's arithmetic in the factorisation: replicated factor -> every output bit-identical
+    (the log-determinant's all-reduce adds the ranks' partial sums, so it may differ in the last bits); distributed solves
+    reduce partial products over the ranks -> 1e-12.  Both against the oracle; fit_predict and the gradient on both."""
+    monkeypatch.setenv("GPX_NB_SHARD", str(nb))
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", str(repl))
+    X, y, Xs = synthetic_problem(N, 3, 333, seed=N + ndev)
+    ref = OracleGP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    out = {}
+    for deal in ("snake", "cyclic"):
+        monkeypatch.setenv("GPX_SHARD_DEAL", deal)
+        with GP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0, devices=ndev, oversubscribe=True) as gp:
+            mean, var = gp.fit(X, y).predict(Xs)
+            check(mean, var, gp.alpha_, gp.log_det_, ref, mr, vr)
+            m1, v1 = gp.fit_predict(X, y, Xs)
+            lml, grad = gp.lml_gradient()
+            out[deal] = (mean, var, gp.alpha_.copy(), gp.log_det_, m1, v1, lml, grad)
+    a, b = out["snake"], out["cyclic"]
+    if repl:
+        for i in (0, 1, 2, 4, 5):
+            assert np.array_equal(a[i], b[i]), i
+    else:
+        for i in (0, 1, 2, 4, 5):
+            assert np.max(np.abs(a[i] - b[i])) <= 1e-12 * max(1.0, np.max(np.abs(b[i]))), i
+    assert abs(a[3] - b[3]) <= 1e-13 * abs(b[3]) and abs(a[6] - b[6]) <= 1e-12 * abs(b[6])
+    assert np.max(np.abs(a[7] - b[7])) <= 1e-9 * np.max(np.abs(b[7]))
+    go = ref.lml_gradient()
+    assert np.max(np.abs(a[7] - go)) <= 1e-8 * np.max(np.abs(go))

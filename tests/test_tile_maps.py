@@ -67,6 +67,68 @@ def test_staircase_map_random(gpx):
         assert len(got) == len(set(got)) == len(want) and set(got) == want, (tm, tn, P, tpb, c)
 
 
+def dealt_staircase(tm, tn, P, tpb, r, lbf, gc0, snake):
+    from gaussianprocesspathmodelling_amd import dist as gdist
+    blocks = gdist.blocks_owned(r, 100000 // max(1, tpb) + 4 * P, P, snake)   # (far more blocks than any case asks for)
+    want = set()
+    for ti in range(tm):
+        lim = (blocks[lbf + ti // tpb] - gc0) * tpb + ti % tpb
+        want |= {(ti, tj) for tj in range(min(lim, tn - 1) + 1)}
+    return want
+
+
+def test_staircase_under_both_dealings(gpx):
+    """Round 4: the staircase of a rank's trailing update under the cyclic and the snake dealing of row blocks
+    (gpx_debug_stair_map: local tile row -> the row block's place in the dealing), against the Python mirror of the dealing —
+    every owned tile once — and the per-panel balance of TILES over the ranks that the snake is for (P = 8, nb = 512, N = 65536)."""
+    rng = np.random.default_rng(9)
+    for case in range(80):
+        snake = case % 2
+        tpb = int(rng.choice([1, 2, 4, 8]))
+        P = int(rng.integers(1, 9))
+        r = int(rng.integers(0, P))
+        from gaussianprocesspathmodelling_amd import dist as gdist
+        own = gdist.blocks_owned(r, 40 * P, P, bool(snake))
+        p = int(rng.integers(0, 6 * P))                      # panel being applied: columns from block gc0 = p + 2 on
+        gc0 = p + 2
+        lbf = gdist.lb0(p + 1, r, P, bool(snake))            # first own block beyond block p + 1
+        nrows = int(rng.integers(1, 6))
+        tm = nrows * tpb
+        tn = int(rng.integers(1, (own[lbf + nrows - 1] - gc0 + 1) * tpb + 1))
+        cap = tm * tn + 64
+        out = np.empty((cap, 2), dtype=np.int32)
+        count = C.c_int64(0)
+        rc = gpx.gpx_debug_stair_map(tm, tn, P, tpb, r, lbf, gc0, snake, out.ctypes.data_as(C.POINTER(C.c_int32)), cap,
+                                     C.byref(count))
+        assert rc == 0, (tm, tn, P, tpb, r, lbf, gc0, snake)
+        got = [tuple(q) for q in out[:count.value].tolist()]
+        want = dealt_staircase(tm, tn, P, tpb, r, lbf, gc0, bool(snake))
+        assert len(got) == len(set(got)) == len(want) and set(got) == want, (tm, tn, P, tpb, r, lbf, gc0, snake)
+
+    def tiles_per_rank(snake, nblk=128, P=8, tpb=4):
+        from gaussianprocesspathmodelling_amd import dist as gdist
+        worst = mean = 0
+        for p in range(0, nblk - 2, 9):
+            per = []
+            for r in range(P):
+                lbf = gdist.lb0(p + 1, r, P, snake)
+                nown = gdist.lb0(nblk - 1, r, P, snake) - lbf
+                if nown <= 0:
+                    per.append(0)
+                    continue
+                tm, tn = nown * tpb, (nblk - p - 2) * tpb
+                cap = tm * tn + 64
+                out = np.empty((cap, 2), dtype=np.int32)
+                count = C.c_int64(0)
+                assert gpx.gpx_debug_stair_map(tm, tn, P, tpb, r, lbf, p + 2, int(snake),
+                                               out.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(count)) == 0
+                per.append(count.value)
+            worst += max(per)
+            mean += sum(per) / P
+        return worst / mean
+    assert tiles_per_rank(True) < 1.02 < 1.07 < tiles_per_rank(False)
+
+
 def test_first_super_tiles_are_compact(gpx):
     """The L2 argument of DESIGN.md §3.1: 64 consecutive launch slots of one XCD chunk touch at
     most 16 panel row blocks (8 rows + 8 columns of tiles) while super-tiles are full."""

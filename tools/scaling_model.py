@@ -39,11 +39,30 @@ LINK = 153e9 * 0.70                                 # sustained per-link payload
 LAT = 30e-6                                         # latency of one RCCL collective on the look-ahead stream (assumption)
 
 
-def pick_nb(N, P):
+def pick_nb(N, P, snake=True):
+    """the library's balance rule (gpx_shard.inc): at least 8 blocks per rank under the snake dealing, 16 under the cyclic"""
     nb = 1024
-    while nb > 256 and nb * 16 * P > N:
+    while nb > 256 and nb * (8 if snake else 16) * P > N:
         nb //= 2
     return nb
+
+
+def owner(g, P, snake):
+    """gpx_internal.h: Deal — cyclic (rounds 1-3) or snake (round 4: rounds of 2 P blocks dealt 0 .. P-1, P-1 .. 0)."""
+    if not snake:
+        return g % P
+    pos = g % (2 * P)
+    return pos if pos < P else 2 * P - 1 - pos
+
+
+def heaviest_share(nblk, p, P, snake):
+    """update of panel p: the heaviest rank's work over the mean (row block g > p + 1 costs g - p - 1.5 block products in
+    the REST and one in STRIP_B) — the ranks meet at every panel, so the heaviest one sets the pace."""
+    w = [0.0] * P
+    for g in range(p + 2, nblk):
+        w[owner(g, P, snake)] += (g - p - 1.5) + 1.0
+    tot = sum(w)
+    return max(w) * P / tot if tot > 0 else 1.0
 
 
 def chain_time(idle_work, busy_for):
@@ -54,8 +73,8 @@ def chain_time(idle_work, busy_for):
     return busy_for + idle_work - busy_for / CHAIN_STRETCH
 
 
-def fit_time(N, P, nb=None, split=True, replicated=True):
-    nb = nb or pick_nb(N, P)
+def fit_time(N, P, nb=None, split=True, replicated=True, snake=True):
+    nb = nb or pick_nb(N, P, snake)
     rate = RATE[nb] if P > 1 else RATE_1GPU
     nblk = N // nb
     diag_idle = nb / 128 * CHAIN_US_PER_128 * 1e-6
@@ -65,9 +84,10 @@ def fit_time(N, P, nb=None, split=True, replicated=True):
     comm_bytes = 0.0
     for p in range(nblk - 1):
         n = N - (p + 1) * nb                         # trailing rows
-        strip = 2.0 * (n * nb - nb * (nb - 1) / 2) * nb / P / rate
+        heavy = heaviest_share(nblk, p, P, snake) if P > 1 else 1.0
+        strip = 2.0 * (n * nb - nb * (nb - 1) / 2) * nb / P / rate * heavy
         rest_n = n - nb
-        rest = max(0.0, rest_n * (rest_n + 1.0) * nb / P / rate)
+        rest = max(0.0, rest_n * (rest_n + 1.0) * nb / P / rate) * heavy
         # chain of panel p+1 (runs beside REST(p))
         rows = max(0, n - nb)
         bc_bytes = (2 * nb * nb + 64 * nb) * 8
@@ -79,7 +99,7 @@ def fit_time(N, P, nb=None, split=True, replicated=True):
         comm_bytes += (bc_bytes + ag_bytes) * (P - 1) / P if P > 1 else 0
         if split:   # round 4: only the next diagonal block's update on the chain; the rest of the strip with the REST
             strip_d = max(STRIP_D_FLOOR * nb / 1024, nb * (nb + 1.0) * nb / 30e12)
-            strip_b = max(0.0, 2.0 * (n - nb) * nb * nb / P / rate)
+            strip_b = max(0.0, 2.0 * (n - nb) * nb * nb / P / rate) * heavy
             main = strip_b + rest   # (replicated: panel p goes into the full factor on the copy stream, beside the REST)
             ch = strip_d + chain_time(diag_idle, main) + bcast + solve + gather
             step = max(main, ch)
@@ -122,7 +142,8 @@ def table(N, M, Ps, replicated, label):
     base = None
     for P in Ps:
         f = fit_time(N, P, replicated=replicated)
-        f["fit_s_round3_schedule"] = fit_time(N, P, split=False, replicated=replicated)["fit_s"]
+        f["fit_s_round3_schedule"] = fit_time(N, P, split=False, replicated=replicated, snake=False)["fit_s"]
+        f["fit_s_cyclic"] = fit_time(N, P, replicated=replicated, snake=False)["fit_s"]
         pr = predict_time(N, M, P, replicated and P > 1) if P > 1 else predict_time(N, M, 1, True)
         extra = (ZSOLVE if replicated or P == 1 else 2 * (N // f["nb"]) * (LAT + 35e-6))   # alpha solves (distributed: not overlapped)
         tot = f["fit_s"] + pr + extra
@@ -131,11 +152,11 @@ def table(N, M, Ps, replicated, label):
         rows.append({"P": P, **f, "predict_s": pr, "solves_s": extra, "total_s": tot, "points_per_s": (N + M) / tot,
                      "speedup": base / tot, "efficiency": base / tot / P, "frac_peak": flops / tot / (P * 78.6e12)})
     print(f"\n**{label}** (N = {N}, M = {M})\n")
-    print("| P | nb | fit ms | (round-3 schedule) | of which exposed chain ms | chain first exposed at panel | predict ms | solves ms | total ms | points/s | speed-up | efficiency | fraction of P x 78.6 TF | received per rank GB |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| P | nb | fit ms | (cyclic dealing) | (round-3 schedule, cyclic) | of which exposed chain ms | chain first exposed at panel | predict ms | solves ms | total ms | points/s | speed-up | efficiency | fraction of P x 78.6 TF | received per rank GB |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         several = len(rows) > 1
-        cells = [r["P"], r["nb"], f"{r['fit_s'] * 1e3:.0f}", f"{r['fit_s_round3_schedule'] * 1e3:.0f}", f"{r['exposed_chain_s'] * 1e3:.0f}",
+        cells = [r["P"], r["nb"], f"{r['fit_s'] * 1e3:.0f}", f"{r['fit_s_cyclic'] * 1e3:.0f}", f"{r['fit_s_round3_schedule'] * 1e3:.0f}", f"{r['exposed_chain_s'] * 1e3:.0f}",
                  f"{r['first_exposed_panel']} of {r['panels']}", f"{r['predict_s'] * 1e3:.0f}", f"{r['solves_s'] * 1e3:.0f}",
                  f"{r['total_s'] * 1e3:.0f}", f"{r['points_per_s']:.0f}", f"{r['speedup']:.2f}" if several else "-",
                  f"{r['efficiency']:.2f}" if several else "-", f"{r['frac_peak']:.2f}", f"{r['recv_GB_per_rank']:.1f}"]
