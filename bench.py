@@ -81,11 +81,14 @@ def synthetic(N, d, M, seed):
     return X, y, Xs
 
 
+DEALING = "cyclic" if os.environ.get("GPX_SHARD_DEAL", "snake") in ("cyclic", "0") else "snake"   # gpx_internal.h: Deal
+
+
 def shard_block(N, world):
     """Row-block height the library picks for the shard (gpx_shard.inc: >= 8 blocks per rank under the snake dealing of
     round 4, >= 16 under GPX_SHARD_DEAL=cyclic)."""
     nb = 1024
-    per_rank = 16 if os.environ.get("GPX_SHARD_DEAL", "snake") in ("cyclic", "0") else 8
+    per_rank = 16 if DEALING == "cyclic" else 8
     while nb > 256 and nb * per_rank * world > N:
         nb //= 2
     return int(os.environ.get("GPX_NB_SHARD", nb))
@@ -716,8 +719,8 @@ def run(args):
                        "kernel": kernel, "block": args.block or (shard_block(N, world) if shard else
                                                                 (2048 if N >= int(os.environ.get("GPX_NB_WIDE_FROM", "40960") or 0) > 0 else 1024)),
                        "parallelism": "1 gpu" if world == 1 else
-                       (f"row-block-cyclic shard over {world} gpus (one process, in-process peer-copy transport)" if group else
-                        f"row-block-cyclic shard over {world} gpus ({'RCCL' if args.backend == 'nccl' else 'host collectives, rehearsal'})" if shard
+                       (f"row-block shard ({DEALING} dealing) over {world} gpus (one process, in-process peer-copy transport)" if group else
+                        f"row-block shard ({DEALING} dealing) over {world} gpus ({'RCCL' if args.backend == 'nccl' else 'host collectives, rehearsal'})" if shard
                         else f"{world} independent replicas")},
             "outputs_finite": ok,
             "shard_check": shard_check,
