@@ -48,7 +48,7 @@ class GP:
         n > 0: exactly n iterations
     device : HIP device ordinal (default: LOCAL_RANK or 0)
     devices : several GPUs from ONE ordinary Python process: an int n (devices
-        0..n-1) or a list of HIP ordinals.  The Gram matrix is sharded in block-cyclic row blocks
+        0..n-1) or a list of HIP ordinals.  The Gram matrix is sharded in row blocks dealt over the devices (snake dealing: balanced row work)
         over them; one worker thread per device lives inside ``fit`` / ``predict``, which stay
         plain blocking calls — no launcher, no ``torch.distributed``.  ``devices=1`` / ``[i]`` is
         the single-GPU path on that device — unless ``transport`` is given explicitly: then it is a
