@@ -58,6 +58,20 @@ def main():
         else:                                   # 0: let the library choose from N and world
             os.environ.pop("GPX_NB_SHARD", None)
         from gaussianprocesspathmodelling_amd import GP
+        if os.environ.get("SHARD_DISAGREE") == "1":      # rank 1's environment differs: the library must notice, on every rank
+            if rank == 1:
+                os.environ["GPX_SHARD_DEAL"] = "cyclic"
+            from gaussianprocesspathmodelling_amd import GpxError
+            with GP(kernel, ls, sf2, sn2, jitter=0.0, device=0, world=world, rank=rank, comm="host") as gp:
+                try:
+                    gp.fit(X, y)
+                    res = dict(error="")
+                except GpxError as e:
+                    res = dict(error=str(e))
+            np.savez(out + f".rank{rank}.npz", **res)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         dtype = os.environ.get("SHARD_DTYPE", "float64")
         if dtype == "float32":
             X, y, Xs = (v.astype(np.float32) for v in (X, y, Xs))

@@ -79,6 +79,14 @@ def test_sharded_ranks_share_one_gpu(tmp_path, world, kernel, nb, N, repl):
     assert np.array_equal(res[0]["mean"], res[-1]["mean"]) and np.array_equal(res[0]["var"], res[-1]["var"])
 
 
+def test_ranks_that_disagree_on_the_dealing_fail_together(tmp_path):
+    """Round 4: block height and dealing come from each rank's ENVIRONMENT; ranks that disagree would exchange differently
+    shaped pieces and return wrong numbers silently.  One min-all-reduce before anything is exchanged: every rank raises."""
+    res = run_ranks("gpu", 2, tmp_path, {"SHARD_DISAGREE": "1", "SHARD_N": "700", "SHARD_NB": "128"}, timeout=300)
+    for r in res:
+        assert "disagree" in str(r["error"]), r["error"]
+
+
 @pytest.mark.parametrize("world,kernel,nb,N,M,repl,dtype", [
     (2, "rbf", 128, 700, 90, 0, "float64"), (3, "matern52", 128, 700, 300, 1, "float64"), (4, "rbf", 512, 3300, 1000, 0, "float64"),
     (2, "rbf", 128, 100, 5, 0, "float64"), (3, "rbf", 128, 250, 2, 1, "float64"), (2, "rbf", 0, 9000, 600, -1, "float64"),
