@@ -5,6 +5,7 @@ is a number measured on ONE MI355X (cited) or a stated assumption about xGMI; wh
 exists, the per-term deviations point at the cause.
 
     python tools/scaling_model.py            # prints the markdown tables of DESIGN.md §6
+    python tools/scaling_model.py --compare FILE [FILE ...]   # measured bench.py JSON lines against the model, term by term
 
 Schedule modelled (csrc/gpx_shard.inc, round 4): row blocks of height nb dealt block-cyclically; per panel p
   main stream      : STRIP_B(p) (own rows below block p+1, its columns) -> REST(p)          (own rows; MFMA-bound)
@@ -164,7 +165,49 @@ def table(N, M, Ps, replicated, label):
     return rows
 
 
+def compare(paths):
+    """Measured bench.py lines (one JSON object per line, e.g. the driver's SCALE record or gpurun_out files) against the
+    model, term by term: which prediction a first multi-GPU run confirms and which it does not."""
+    import sys
+    lines = []
+    for path in paths:
+        for raw in open(path).read().splitlines():
+            raw = raw.strip()
+            if not raw.startswith("{"):
+                continue
+            try:
+                d = json.loads(raw)
+            except ValueError:
+                continue
+            for cand in (d, d.get("parsed") if isinstance(d, dict) else None):   # bare bench line, or a driver record wrapping it
+                if isinstance(cand, dict) and "n_gpus" in cand and "phases_ms" in cand:
+                    lines.append(cand)
+    if not lines:
+        print("no bench lines with n_gpus and phases_ms found", file=sys.stderr)
+        return 1
+    print("| P | block | measured step ms | model | measured fit | model | measured chol | measured comm (inside fit) | measured predict | model | measured solve | model |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for d in sorted(lines, key=lambda x: x["n_gpus"]):
+        P = int(d["n_gpus"])
+        cfg = d.get("config", {})
+        N, M = int(cfg.get("N", 65536)), int(cfg.get("M", 4096))
+        nb = int(cfg.get("block") or pick_nb(N, P))
+        ph = d["phases_ms"]
+        repl = N <= 131072
+        f = fit_time(N, P, nb=nb if P > 1 else None, replicated=repl)
+        pr = predict_time(N, M, P, repl and P > 1) if P > 1 else predict_time(N, M, 1, True)
+        sol = ZSOLVE if (repl or P == 1) else 2 * (N // f["nb"]) * (LAT + 35e-6)
+        print(f"| {P} | {nb} | {d['ms_per_step']:.1f} | {(f['fit_s'] + pr + sol) * 1e3:.0f} | {ph.get('fit_total', 0):.1f} | {f['fit_s'] * 1e3:.0f} | "
+              f"{ph.get('chol', 0):.1f} | {ph.get('comm', 0):.1f} | {ph.get('predict_total', 0):.1f} | {pr * 1e3:.0f} | {ph.get('solve', 0):.1f} | {sol * 1e3:.1f} |")
+        for r, pr_ in enumerate(d.get("per_rank_phases_ms") or []):
+            print(f"|   rank {r} | | | | {pr_.get('fit_total')} | | {pr_.get('chol')} | {pr_.get('comm')} | {pr_.get('predict_total')} | | {pr_.get('solve')} | |")
+    return 0
+
+
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 2 and sys.argv[1] == "--compare":
+        raise SystemExit(compare(sys.argv[2:]))
     out = {"C3": table(65536, 4096, (1, 2, 4, 8), True, "C3 sharded, replicated factor (the `bench.py --gpus N` path)"),
            "C4": table(262144, 4096, (8,), False, "C4, distributed solves (550 GB Gram matrix: 8 GPUs only)")}
     print("\n```json\n" + json.dumps({"inputs": {"rate": {str(k): v for k, v in RATE.items()}, "rate_1gpu": RATE_1GPU,
