@@ -748,7 +748,7 @@ def run(args):
         chol_ms = acc["chol"] / steps
         out["cholesky_tflops"] = (N ** 3 / 3.0) / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0
         if shard:   # the sharded update has no per-launch flop bookkeeping: rate the whole factorisation
-            out["roofline"].update(kernel="blocked Cholesky, all ranks (gemm_nt_kernel<128> with block-cyclic mask)",
+            out["roofline"].update(kernel="blocked Cholesky, all ranks (trailing updates: gemm_nt_stair_kernel<128>, the staircase of the dealt row blocks)",
                                    traffic=None, traffic_source=None,
                                    achieved=out["cholesky_tflops"], peak=peak_mfma * world,
                                    frac=out["cholesky_tflops"] / (peak_mfma * world))
