@@ -79,6 +79,7 @@ struct gpx_handle {
   hipStream_t st2 = nullptr;  // look-ahead (panel) stream, high priority
   hipStream_t st3 = nullptr;  // side stream of the diagonal chain: in-block SYRKs, block inverses
   hipStream_t st4 = nullptr;  // copy stream: solved panels / blocks back into their matrices
+  hipStream_t st5 = nullptr;  // sharded factorisation: the owner's diagonal chain beside the all-gather of the previous panel (created by the first sharded fit)
   std::string err;
   gpx_timings tm{};
   // fitted state
@@ -1781,6 +1782,7 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st2) (void)hipStreamSynchronize(h->st2);
   if (h->st3) (void)hipStreamSynchronize(h->st3);
   if (h->st4) (void)hipStreamSynchronize(h->st4);
+  if (h->st5) (void)hipStreamSynchronize(h->st5);
   for (DevBuf* b : {&h->X, &h->Xs, &h->ls, &h->K, &h->Winv, &h->P, &h->YT, &h->Y, &h->scalars,
                     &h->info, &h->Q, &h->Qs, &h->VT, &h->MT, &h->MTpart, &h->var, &h->meanout, &h->G,
                     &h->Dbuf, &h->Sbuf, &h->YTloc, &h->Cneg, &h->Sv, &h->AT, &h->Lfull, &h->GatherS,
@@ -1793,6 +1795,7 @@ void gpx_destroy(gpx_handle* h) {
   if (h->st2) (void)hipStreamDestroy(h->st2);
   if (h->st3) (void)hipStreamDestroy(h->st3);
   if (h->st4) (void)hipStreamDestroy(h->st4);
+  if (h->st5) (void)hipStreamDestroy(h->st5);
   delete h;
 }
 
@@ -1972,7 +1975,7 @@ int gpx_release_scratch(gpx_handle* h) try {
     hs.push_back(h);
   for (gpx_handle* m : hs) {
     HIPCHK(h, hipSetDevice(m->cfg.device));
-    for (hipStream_t sx : {m->st, m->st2, m->st3, m->st4})
+    for (hipStream_t sx : {m->st, m->st2, m->st3, m->st4, m->st5})
       if (sx) HIPCHK(h, hipStreamSynchronize(sx));
     for (DevBuf* b : {&m->ZT, &m->ZTloc, &m->ZTpack, &m->gpart, &m->MTpart, &m->VT, &m->Tsol, &m->Q, &m->Qs, &m->MT, &m->Sv, &m->Q64, &m->Qs64, &m->Q32,
                       &m->M64, &m->GatherS, &m->GatherR, &m->outM, &m->outV})

@@ -349,7 +349,10 @@ def test_group_split_schedule_is_bit_identical_to_the_round3_schedule(monkeypatc
     ref = OracleGP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
     mr, vr = ref.predict(Xs)
     check(base[0], base[1], base[2], base[3], ref, mr, vr)
-    for env in ({"GPX_SPLIT_STRIP": "0"}, {"GPX_REST_SPLIT": "0"}, {"GPX_REST_SPLIT": "1"}, {"GPX_REST_SPLIT": "1000"}):
+    # (round 4 end: also the owner's diagonal chain on a stream of its own beside the previous panel's all-gather — default
+    #  from 4 ranks on — forced on and off, and the replicated factor's panel copy on the main stream)
+    for env in ({"GPX_SPLIT_STRIP": "0"}, {"GPX_REST_SPLIT": "0"}, {"GPX_REST_SPLIT": "1"}, {"GPX_REST_SPLIT": "1000"},
+                {"GPX_SHARD_TWO_PIPE": "0"}, {"GPX_SHARD_TWO_PIPE": "1"}, {"GPX_REPL_COPY_SIDE": "0"}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         got = run()

@@ -11,6 +11,9 @@ Schedule modelled (csrc/gpx_shard.inc, round 4): row blocks of height nb dealt b
   main stream      : STRIP_B(p) (own rows below block p+1, its columns) -> REST(p)          (own rows; MFMA-bound)
   look-ahead stream: STRIP_D(p) (the next diagonal block only, on its owner) -> diagonal block p+1 -> broadcast
                      [L_pp | inverses | W_p] -> every rank solves its rows of panel p+1 -> all-gather
+                     (from 4 ranks on the owner runs STRIP_D and the diagonal block on a stream of its own, right behind ITS
+                     solve of panel p and beside the all-gather of panel p: per panel solve + max(STRIP_D + block + broadcast,
+                     all-gather + STRIP_B) instead of their sum)
                      (no un-permute behind it any more: the update kernels read the gathered panel in place; the replicated
                      factor's copy of the panel is written on the copy stream beside the REST)
   step time        = max(STRIP_B(p) + REST(p), chain(p+1))
@@ -74,7 +77,7 @@ def chain_time(idle_work, busy_for):
     return busy_for + idle_work - busy_for / CHAIN_STRETCH
 
 
-def fit_time(N, P, nb=None, split=True, replicated=True, snake=True):
+def fit_time(N, P, nb=None, split=True, replicated=True, snake=True, two_pipe=True):
     nb = nb or pick_nb(N, P, snake)
     rate = RATE[nb] if P > 1 else RATE_1GPU
     nblk = N // nb
@@ -102,7 +105,11 @@ def fit_time(N, P, nb=None, split=True, replicated=True, snake=True):
             strip_d = max(STRIP_D_FLOOR * nb / 1024, nb * (nb + 1.0) * nb / 30e12)
             strip_b = max(0.0, 2.0 * (n - nb) * nb * nb / P / rate) * heavy
             main = strip_b + rest   # (replicated: panel p goes into the full factor on the copy stream, beside the REST)
-            ch = strip_d + chain_time(diag_idle, main) + bcast + solve + gather
+            diag_path = strip_d + chain_time(diag_idle, main) + bcast
+            if two_pipe and P >= 4:   # the owner's chain beside the previous panel's all-gather: the gather leaves the cycle
+                ch = solve + max(diag_path, gather + strip_b)
+            else:
+                ch = diag_path + solve + gather
             step = max(main, ch)
             over = ch - main
         else:
@@ -144,7 +151,8 @@ def table(N, M, Ps, replicated, label):
     for P in Ps:
         f = fit_time(N, P, replicated=replicated)
         f["fit_s_round3_schedule"] = fit_time(N, P, split=False, replicated=replicated, snake=False)["fit_s"]
-        f["fit_s_cyclic"] = fit_time(N, P, replicated=replicated, snake=False)["fit_s"]
+        f["fit_s_cyclic"] = fit_time(N, P, replicated=replicated, snake=False, two_pipe=False)["fit_s"]
+        f["fit_s_one_pipe"] = fit_time(N, P, replicated=replicated, two_pipe=False)["fit_s"]
         pr = predict_time(N, M, P, replicated and P > 1) if P > 1 else predict_time(N, M, 1, True)
         extra = (ZSOLVE if replicated or P == 1 else 2 * (N // f["nb"]) * (LAT + 35e-6))   # alpha solves (distributed: not overlapped)
         tot = f["fit_s"] + pr + extra
@@ -153,11 +161,11 @@ def table(N, M, Ps, replicated, label):
         rows.append({"P": P, **f, "predict_s": pr, "solves_s": extra, "total_s": tot, "points_per_s": (N + M) / tot,
                      "speedup": base / tot, "efficiency": base / tot / P, "frac_peak": flops / tot / (P * 78.6e12)})
     print(f"\n**{label}** (N = {N}, M = {M})\n")
-    print("| P | nb | fit ms | (cyclic dealing) | (round-3 schedule, cyclic) | of which exposed chain ms | chain first exposed at panel | predict ms | solves ms | total ms | points/s | speed-up | efficiency | fraction of P x 78.6 TF | received per rank GB |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| P | nb | fit ms | (one chain stream) | (cyclic dealing, one chain stream) | (round-3 schedule, cyclic) | of which exposed chain ms | chain first exposed at panel | predict ms | solves ms | total ms | points/s | speed-up | efficiency | fraction of P x 78.6 TF | received per rank GB |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         several = len(rows) > 1
-        cells = [r["P"], r["nb"], f"{r['fit_s'] * 1e3:.0f}", f"{r['fit_s_cyclic'] * 1e3:.0f}", f"{r['fit_s_round3_schedule'] * 1e3:.0f}", f"{r['exposed_chain_s'] * 1e3:.0f}",
+        cells = [r["P"], r["nb"], f"{r['fit_s'] * 1e3:.0f}", f"{r['fit_s_one_pipe'] * 1e3:.0f}", f"{r['fit_s_cyclic'] * 1e3:.0f}", f"{r['fit_s_round3_schedule'] * 1e3:.0f}", f"{r['exposed_chain_s'] * 1e3:.0f}",
                  f"{r['first_exposed_panel']} of {r['panels']}", f"{r['predict_s'] * 1e3:.0f}", f"{r['solves_s'] * 1e3:.0f}",
                  f"{r['total_s'] * 1e3:.0f}", f"{r['points_per_s']:.0f}", f"{r['speedup']:.2f}" if several else "-",
                  f"{r['efficiency']:.2f}" if several else "-", f"{r['frac_peak']:.2f}", f"{r['recv_GB_per_rank']:.1f}"]
