@@ -11,9 +11,11 @@ lib = _abi.load()
 
 
 def run(N, M, kw):
+    kw = dict(kw)
+    one_pass = kw.pop("one_pass", False)
     X, y, Xs = synthetic_problem(N, 3, M, seed=N)
     with GP("matern52", 0.25, 1.5, 1e-2, jitter=0.0, **kw) as gp:
-        mean, var = gp.fit(X, y).predict(Xs)
+        mean, var = gp.fit_predict(X, y, Xs) if one_pass else gp.fit(X, y).predict(Xs)
         return [mean, var, gp.alpha_.copy(), np.float64(gp.log_det_)]
 
 
@@ -22,7 +24,11 @@ for N, M, kw, env in ((32768, 2048, {}, {}),
                       (49152, 1024, {}, {}),          # round 4: 2048-wide panels (the library's choice from N = 40960 on)
                       (32768, 1024, {"devices": 4, "oversubscribe": True, "dtype": "mixed"}, {"GPX_SHARD_REPLICATE": "0"}),   # round 4: mixed shard, distributed refinement
                       (16384, 1024, {"devices": 4, "oversubscribe": True}, {"GPX_SHARD_REPLICATE": "0"}),
-                      (32768, 1024, {"devices": 8, "oversubscribe": True}, {"GPX_SHARD_REPLICATE": "0"})):
+                      (32768, 1024, {"devices": 8, "oversubscribe": True}, {"GPX_SHARD_REPLICATE": "0"}),
+                      # end of round 4: the one pass on shards (query rows riding), snake dealing, the owner's chain on its own
+                      # stream (from 4 ranks on), the replicated factor's panel copy on the copy stream
+                      (32768, 2048, {"devices": 8, "oversubscribe": True, "one_pass": True}, {"GPX_SHARD_REPLICATE": "0"}),
+                      (24576, 2048, {"devices": 4, "oversubscribe": True, "one_pass": True}, {"GPX_SHARD_REPLICATE": "1"})):
     os.environ.update(env)
     base = run(N, M, kw)
     same = True
