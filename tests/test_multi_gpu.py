@@ -126,3 +126,43 @@ def test_two_devices_fp32_and_mixed_shards(monkeypatch, transport, dtype, repl):
             assert em <= 1e-6 and ea <= 1e-7 and ev <= 2e-3
         else:
             assert np.max(np.abs(mean - mr)) <= 2e-3 * np.max(np.abs(mr)) and ev <= 2e-3
+
+
+@needs2
+@pytest.mark.parametrize("transport", ["local", "rccl"])
+@pytest.mark.parametrize("repl", ["0", "1"])
+def test_two_devices_one_pass_and_both_dealings(monkeypatch, transport, repl):
+    """Round 4: ``fit_predict`` riding through the sharded factorisation, the snake and the cyclic dealing of the row blocks,
+    the owner's chain on its own stream forced on (its default starts at 4 ranks) — on two REAL devices."""
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", repl)
+    monkeypatch.setenv("GPX_NB_SHARD", "512")
+    monkeypatch.setenv("GPX_SHARD_TWO_PIPE", "1")
+    X, y, Xs = synthetic_problem(9000, 3, 700, seed=22)
+    ref = OracleGP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    out = {}
+    for deal in ("snake", "cyclic"):
+        monkeypatch.setenv("GPX_SHARD_DEAL", deal)
+        with GP("matern52", (0.3, 0.2, 0.25), 1.5, 1e-2, jitter=0.0, devices=[0, 1], transport=transport) as gp:
+            mean, var = gp.fit_predict(X, y, Xs)
+            check(gp, mean, var, ref, mr, vr)
+            m2, v2 = gp.predict(Xs)
+            assert np.max(np.abs(mean - m2)) <= 1e-9 * np.abs(m2).max() and np.max(np.abs(var - v2)) <= 1e-9 * 1.5
+            out[deal] = (mean, var)
+    assert np.max(np.abs(out["snake"][0] - out["cyclic"][0])) <= 1e-12 * np.abs(mr).max()
+
+
+@needs4
+def test_four_devices_defaults_incl_two_pipelines(monkeypatch):
+    """Four real devices: the defaults of round 4 (snake dealing, the owner's chain beside the previous panel's all-gather,
+    gathered panel read in place) over RCCL, distributed solves, one pass."""
+    monkeypatch.setenv("GPX_SHARD_REPLICATE", "0")
+    monkeypatch.setenv("GPX_NB_SHARD", "512")
+    X, y, Xs = synthetic_problem(20000, 3, 1000, seed=23)
+    ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
+    mr, vr = ref.predict(Xs)
+    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0, devices=[0, 1, 2, 3], transport="rccl") as gp:
+        mean, var = gp.fit_predict(X, y, Xs)
+        check(gp, mean, var, ref, mr, vr)
+        m2, v2 = gp.fit(X, y).predict(Xs)
+        assert np.max(np.abs(mean - m2)) <= 1e-9 * np.abs(m2).max()
