@@ -364,7 +364,7 @@ __global__ void flag_probe_set_kernel(unsigned* flag) {
 
 __global__ void spin_kernel(long long cycles) {
   const long long t0 = __builtin_amdgcn_s_memtime();
-  while (__builtin_amdgcn_s_memtime() - t0 < cycles) {
+  while ((long long)__builtin_amdgcn_s_memtime() - t0 < cycles) {
   }
 }
 }  // namespace
