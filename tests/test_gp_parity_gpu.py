@@ -346,6 +346,22 @@ def test_hyperparameter_optimisation_climbs_the_marginal_likelihood():
         assert 0.1 < gp.lengthscale[0] < 0.4 and 0.2 < gp.lengthscale[1] < 0.8
 
 
+_SCHED_BASE = []
+
+
+def schedule_variants_baseline():
+    """(X, y, Xs, oracle mean / var, default-schedule mean / var / alpha / logdet) at N = 12288 — computed by the first
+    variant that runs (no schedule switch is set at that point: monkeypatch sets them after this call), kept for the others."""
+    if not _SCHED_BASE:
+        X, y, Xs = synthetic_problem(12288, 3, 300, seed=31)
+        ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
+        mr, vr = ref.predict(Xs)
+        with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0) as gp:
+            m0, v0 = gp.fit(X, y).predict(Xs)
+            _SCHED_BASE.append((X, y, Xs, mr, vr, m0, v0, gp.alpha_.copy(), gp.log_det_))
+    return _SCHED_BASE[0]
+
+
 @pytest.mark.parametrize("env", [{"GPX_FUSED_STRIP": "1"}, {"GPX_DIAG_STEP": "64"},
                                  {"GPX_FUSED_STRIP": "1", "GPX_DIAG_STEP": "64"}, {"GPX_CU_SELF_RESERVE": "1"}, {"GPX_CU_SELF_RESERVE": "4"},
                                  {"GPX_CHAIN_FLAG": "0"},
@@ -361,12 +377,7 @@ def test_schedule_variants_give_the_same_factorisation(monkeypatch, env):
     N = 12288 with 1024-panels: 11 trailing updates, the first 8 of them large enough to fuse.  Against
     the oracle at 1e-6 and against the default schedule: the fused launch does the same arithmetic per
     tile (bit-identical); the diagonal stepping changes the association inside a 128 x 128 tile only."""
-    X, y, Xs = synthetic_problem(12288, 3, 300, seed=31)
-    ref = OracleGP("rbf", 0.25, 1.5, 1e-2, jitter=0.0).fit(X, y)
-    mr, vr = ref.predict(Xs)
-    with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0) as gp:
-        m0, v0 = gp.fit(X, y).predict(Xs)
-        a0, ld0 = gp.alpha_.copy(), gp.log_det_
+    X, y, Xs, mr, vr, m0, v0, a0, ld0 = schedule_variants_baseline()   # the oracle and the default schedule: once for all variants
     for k_, v_ in env.items():
         monkeypatch.setenv(k_, v_)
     with GP("rbf", 0.25, 1.5, 1e-2, jitter=0.0) as gp:
